@@ -1,0 +1,132 @@
+/*
+ * framewright_hip.h — C-ABI of libframewright_hip.so, the MI355X (gfx950 / CDNA4) drop-in for the
+ * conv-net hot path of FrameWright (Real-ESRGAN upscale, NAFNet temporal denoise, RIFE interpolation).
+ *
+ * The reference (/root/reference, pure Python) has no native boundary of its own: the arithmetic is
+ * delegated to third-party torch modules / external binaries.  Each entry point below therefore names the
+ * reference call it replaces (file:line relative to the reference tree), and INTEGRATION.md shows the
+ * ctypes stub a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = ok, 1 = invalid argument, 2 = GPU out of memory
+ *     (message contains "memory", so restorer.py:1746's tile-downshift retry still triggers),
+ *     3 = HIP runtime error, 4 = internal error.  fw_last_error() returns the message for the calling thread.
+ *   - plain pointers and sizes only; buffers are caller-owned.  `loc` arguments say where a buffer lives:
+ *     FW_HOST (pageable or pinned host memory) or FW_DEVICE (hipMalloc'd / torch.cuda memory on the
+ *     handle's device).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are asynchronous on
+ *     that stream when every buffer is FW_DEVICE; calls with FW_HOST buffers return after the copy back.
+ *   - one handle per GPU; calls on one handle are serialised by an internal mutex, so the reference's
+ *     ThreadPoolExecutor callers (restorer.py:1894) may share a handle.
+ *   - images are H x W x 3 uint8 in BGR order (cv2 convention, plugins/base.py:186-250).
+ */
+#ifndef FRAMEWRIGHT_HIP_H
+#define FRAMEWRIGHT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FW_OK 0
+#define FW_ERR_INVALID 1
+#define FW_ERR_OOM 2
+#define FW_ERR_HIP 3
+#define FW_ERR_INTERNAL 4
+
+#define FW_HOST 0
+#define FW_DEVICE 1
+
+/* operand (MFMA input / activation storage) type; accumulation is always fp32 */
+#define FW_DTYPE_BF16 0
+#define FW_DTYPE_F16 1
+
+typedef struct fw_rrdbnet fw_rrdbnet;
+
+/* -------------------------------------------------------------------------------------------------
+ * Library
+ * ------------------------------------------------------------------------------------------------- */
+
+/* Message of the last failing call on this thread ("" if none).  Never NULL. */
+const char* fw_last_error(void);
+
+/* ABI version of this header (bumped on incompatible change). */
+int fw_abi_version(void);
+
+/* Number of visible HIP devices (0 when there is no GPU; never fails). */
+int fw_device_count(void);
+
+/* -------------------------------------------------------------------------------------------------
+ * Real-ESRGAN: RRDBNet generator
+ * replaces  basicsr RRDBNet construction + RealESRGANer(...) in get_upsampler()
+ *           (processors/pytorch_realesrgan.py:85-173) and upsampler.enhance() (:223,:227;
+ *           processors/enhancement/super_resolution.py:524).
+ * ------------------------------------------------------------------------------------------------- */
+
+/* Create an RRDBNet(num_in_ch=3, num_out_ch=3, num_feat=64, num_block, num_grow_ch=32, scale) on
+ * `device_id`.  scale in {2,4} (pytorch_realesrgan.py:103-129: x4plus nb=23, anime_6B nb=6, x2plus nb=23). */
+int fw_rrdbnet_create(int device_id, int num_block, int scale, int dtype, fw_rrdbnet** out);
+
+/* Upload one convolution.  `key` is the BasicSR state-dict prefix ("conv_first", "body.7.rdb2.conv4",
+ * "conv_body", "conv_up1", "conv_up2", "conv_hr", "conv_last"); weight is torch layout
+ * [cout][cin][3][3] fp32 (host memory), bias [cout] fp32.  Weights are converted to the operand type
+ * (round to nearest even) and packed into MFMA fragments. */
+int fw_rrdbnet_set_conv(fw_rrdbnet* net, const char* key, const float* weight, const float* bias, int cout,
+                        int cin);
+
+/* Verify that every convolution of the architecture has been uploaded. */
+int fw_rrdbnet_finalize(fw_rrdbnet* net);
+
+/* One frame: uint8 BGR H x W x 3 -> uint8 BGR (scale*H) x (scale*W) x 3.
+ * Equivalent to RealESRGANer.enhance(img, outscale=scale) for a 3-channel uint8 image with tile=0,
+ * pre_pad=0: BGR->RGB, /255, (x2 model: reflect mod-pad to even + pixel_unshuffle(2)), RRDBNet forward,
+ * clamp(0,1), *255, round-half-even, RGB->BGR.  If out_rgb_f32 is non-NULL (device memory,
+ * (scale*H) x (scale*W) x 3 floats, RGB order) the un-clamped network output is stored there as well
+ * (used by the parity tests to measure max-abs before quantisation).  out_bgr may be NULL then. */
+int fw_rrdbnet_upscale_u8(fw_rrdbnet* net, const uint8_t* in_bgr, int in_loc, int height, int width,
+                          uint8_t* out_bgr, int out_loc, float* out_rgb_f32, void* stream);
+
+/* Bytes of device workspace the net needs for an H x W input (0 on invalid arguments). */
+size_t fw_rrdbnet_workspace_bytes(const fw_rrdbnet* net, int height, int width);
+
+/* Algorithmic FLOPs (2 x MAC, un-padded channel counts) of one forward on an H x W input. */
+double fw_rrdbnet_flops(const fw_rrdbnet* net, int height, int width);
+
+/* Per-launch timing: when enabled, every conv launch of subsequent upscale calls is bracketed by HIP events on
+ * the launch stream.  fw_rrdbnet_profile_read synchronises the stream and returns the number of conv
+ * launches timed since the last read, their summed duration (ms) and summed algorithmic FLOPs. */
+int fw_rrdbnet_profile_enable(fw_rrdbnet* net, int on);
+int fw_rrdbnet_profile_read(fw_rrdbnet* net, int* launches, double* total_ms, double* total_flops);
+
+/* Release device memory.  NULL is allowed. */
+int fw_rrdbnet_destroy(fw_rrdbnet* net);
+
+/* -------------------------------------------------------------------------------------------------
+ * Operator-level entry points (used by the parity tests; the model calls above use the same kernels).
+ * All pointers are device memory on `device_id`'s current context; tensors are NHWC.
+ * ------------------------------------------------------------------------------------------------- */
+
+/* Pack a torch-layout conv weight [cout][cin][3][3] (host fp32) into MFMA fragments (host uint16 buffer).
+ * Returns the number of uint16 elements (call with dst = NULL to size the buffer).  cout is padded to
+ * 32*cout_tiles, cin to 32*cin_chunks. */
+size_t fw_pack_conv3x3(int dtype, const float* weight, int cout, int cin, int cout_tiles, int cin_chunks,
+                       uint16_t* dst);
+
+/* y = act(conv3x3(x) + bias) written to channels [out_coff, out_coff + 32*cout_tiles) of an NHWC operand-typed
+ * buffer.  x: NHWC operand-typed, in_cstride channels per pixel, first 32*cin_chunks channels are contracted.
+ * upsample2x = 1: x is (H/2 x W/2) and is nearest-neighbour upsampled on the fly (conv_up1/conv_up2 of
+ * aesrgan_face.py:258-266).  res1/res2 (fp32 NHWC, 32*cout_tiles channels, may be NULL):
+ *   res1 == NULL:  y = act(acc + bias)
+ *   res1 != NULL:  y = (acc + bias) * s1 + res1; if res2: y = y * s2 + res2     (aesrgan_face.py:189,204)
+ * out / out_f32 may each be NULL. */
+int fw_conv3x3_nhwc(int dtype, const void* x, int in_cstride, int cin_chunks, int height, int width,
+                    const void* packed_weight, const float* bias, int cout_tiles, int act_lrelu, int upsample2x,
+                    const float* res1, float s1, const float* res2, float s2, void* out, int out_cstride,
+                    int out_coff, float* out_f32, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRAMEWRIGHT_HIP_H */

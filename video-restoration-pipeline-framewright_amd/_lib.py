@@ -1,0 +1,120 @@
+"""ctypes binding of libframewright_hip.so (C-ABI declared in include/framewright_hip.h).
+
+The library is the product: if it is missing or does not load, every operator raises — there is no eager /
+CPU fallback on this path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+from pathlib import Path
+from typing import Optional
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "lib" / "libframewright_hip.so"
+
+FW_OK, FW_ERR_INVALID, FW_ERR_OOM, FW_ERR_HIP, FW_ERR_INTERNAL = 0, 1, 2, 3, 4
+FW_HOST, FW_DEVICE = 0, 1
+FW_DTYPE_BF16, FW_DTYPE_F16 = 0, 1
+DTYPES = {"bf16": FW_DTYPE_BF16, "bfloat16": FW_DTYPE_BF16, "f16": FW_DTYPE_F16, "fp16": FW_DTYPE_F16,
+          "float16": FW_DTYPE_F16, "half": FW_DTYPE_F16}
+
+# every symbol include/framewright_hip.h declares (tests/test_cabi.py checks the header against this list)
+EXPORTS = [
+    "fw_last_error", "fw_abi_version", "fw_device_count",
+    "fw_rrdbnet_create", "fw_rrdbnet_set_conv", "fw_rrdbnet_finalize", "fw_rrdbnet_upscale_u8",
+    "fw_rrdbnet_workspace_bytes", "fw_rrdbnet_flops", "fw_rrdbnet_profile_enable", "fw_rrdbnet_profile_read",
+    "fw_rrdbnet_destroy", "fw_pack_conv3x3", "fw_conv3x3_nhwc",
+]
+
+
+class FramewrightHipError(RuntimeError):
+    """Raised for every failing C-ABI call; ``code`` is the FW_ERR_* status."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(message)
+        self.code = code
+
+
+class FramewrightOutOfMemory(FramewrightHipError):
+    """FW_ERR_OOM — message contains "memory" so reference restorer.py:1746 retries with a smaller tile."""
+
+
+_lock = threading.Lock()
+_lib: Optional[C.CDLL] = None
+
+
+def _declare(lib: C.CDLL) -> None:
+    vp, i32, f32, f64, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
+    lib.fw_last_error.restype = C.c_char_p
+    lib.fw_last_error.argtypes = []
+    lib.fw_abi_version.restype = i32
+    lib.fw_abi_version.argtypes = []
+    lib.fw_device_count.restype = i32
+    lib.fw_device_count.argtypes = []
+    lib.fw_rrdbnet_create.restype = i32
+    lib.fw_rrdbnet_create.argtypes = [i32, i32, i32, i32, C.POINTER(vp)]
+    lib.fw_rrdbnet_set_conv.restype = i32
+    lib.fw_rrdbnet_set_conv.argtypes = [vp, C.c_char_p, vp, vp, i32, i32]
+    lib.fw_rrdbnet_finalize.restype = i32
+    lib.fw_rrdbnet_finalize.argtypes = [vp]
+    lib.fw_rrdbnet_upscale_u8.restype = i32
+    lib.fw_rrdbnet_upscale_u8.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp]
+    lib.fw_rrdbnet_workspace_bytes.restype = sz
+    lib.fw_rrdbnet_workspace_bytes.argtypes = [vp, i32, i32]
+    lib.fw_rrdbnet_flops.restype = f64
+    lib.fw_rrdbnet_flops.argtypes = [vp, i32, i32]
+    lib.fw_rrdbnet_profile_enable.restype = i32
+    lib.fw_rrdbnet_profile_enable.argtypes = [vp, i32]
+    lib.fw_rrdbnet_profile_read.restype = i32
+    lib.fw_rrdbnet_profile_read.argtypes = [vp, C.POINTER(i32), C.POINTER(f64), C.POINTER(f64)]
+    lib.fw_rrdbnet_destroy.restype = i32
+    lib.fw_rrdbnet_destroy.argtypes = [vp]
+    lib.fw_pack_conv3x3.restype = sz
+    lib.fw_pack_conv3x3.argtypes = [i32, vp, i32, i32, i32, i32, vp]
+    lib.fw_conv3x3_nhwc.restype = i32
+    lib.fw_conv3x3_nhwc.argtypes = [i32, vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp, f32, vp, f32, vp, i32,
+                                    i32, vp, vp]
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once).  Raises FramewrightHipError when it is absent — build it with
+    ``python __graft_entry__.py build`` (hipcc, gfx950)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not LIB_PATH.exists():
+            raise FramewrightHipError(FW_ERR_INTERNAL,
+                                      f"{LIB_PATH} not found: the HIP extension is not built "
+                                      "(run `python __graft_entry__.py build`); there is no CPU fallback")
+        # torch bundles its own libamdhip64.so.7; importing it first makes both share ONE HIP runtime, so
+        # torch.cuda device pointers and streams can be handed to the library.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is plumbing, the library also works stand-alone
+            pass
+        try:
+            lib = C.CDLL(str(LIB_PATH))
+        except OSError as e:
+            raise FramewrightHipError(FW_ERR_INTERNAL, f"cannot load {LIB_PATH}: {e}") from e
+        _declare(lib)
+        _lib = lib
+        return lib
+
+
+def check(status: int) -> None:
+    if status == FW_OK:
+        return
+    msg = load().fw_last_error().decode("utf-8", "replace")
+    if status == FW_ERR_OOM:
+        raise FramewrightOutOfMemory(status, msg)
+    raise FramewrightHipError(status, msg)
+
+
+def require_gpu() -> int:
+    """Number of visible devices; raises when there is none (the product path never runs on the CPU)."""
+    n = load().fw_device_count()
+    if n <= 0:
+        raise FramewrightHipError(FW_ERR_HIP, "no HIP device visible: framewright_amd has no CPU fallback")
+    return n

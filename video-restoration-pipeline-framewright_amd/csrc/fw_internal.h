@@ -1,0 +1,80 @@
+// Internal declarations shared by the HIP translation units of libframewright_hip.so.
+// gfx950 (MI355X / CDNA4) only.  Nothing in here is part of the C-ABI; see include/framewright_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <string>
+#include <stdexcept>
+
+namespace fw {
+
+// Operand (MFMA A/B and activation storage) type.  Accumulation is always fp32.
+enum DType : int { DT_BF16 = 0, DT_F16 = 1 };
+
+// ---- conv3x3 (stride 1, zero pad 1) implicit GEMM on MFMA ---------------------------------
+// Input : NHWC, operand-typed, `in_cstride` channels per pixel, the conv reads the first
+//         32*cin_chunks channels (a prefix of the residual-dense "concat" buffer).
+// Output: depends on the epilogue.
+enum ConvEpilogue : int {
+    EPI_STORE = 0,     // y = act(acc + bias)                    -> typed NHWC slice (+ optional fp32 copy)
+    EPI_RESIDUAL = 1,  // y = (acc+bias)*s1 + res1 [; y = y*s2 + res2] -> fp32 trunk + typed NHWC slice
+    EPI_IMAGE = 2,     // 3 output channels: RGB float and/or clamp->x255->rint->uint8 BGR
+};
+
+struct ConvParams {
+    const void* in;        // typed NHWC
+    int in_cstride;        // channels per pixel of the input buffer
+    int cin_chunks;        // number of 32-channel chunks to contract over
+    int H, W;              // OUTPUT height/width (input is H/2 x W/2 when upsample2x)
+    const void* wpk;       // packed weight fragments (see pack_conv3x3_weights)
+    const float* bias;     // [32*cout_tiles] (zero padded)
+    void* out;             // typed NHWC output (may be null for EPI_IMAGE)
+    int out_cstride;       // channels per pixel of the output buffer
+    int out_coff;          // first channel written
+    float* out_f32;        // optional fp32 NHWC copy, stride = 32*cout_tiles (EPI_STORE/EPI_RESIDUAL)
+    const float* res1;     // fp32 NHWC stride 32*cout_tiles
+    const float* res2;     // optional second residual
+    float s1, s2;
+    uint8_t* out_u8;       // EPI_IMAGE: HxWx3 BGR uint8 (optional)
+    float* out_rgb;        // EPI_IMAGE: HxWx3 RGB float, un-clamped (optional)
+    int img_H, img_W;      // EPI_IMAGE: size of the stored image (crop of the H x W conv output; mod-pad removal)
+    int act;               // 1 = LeakyReLU(0.2) (EPI_STORE only)
+    int upsample2x;        // 1 = input is nearest-neighbour x2 upsampled on the fly
+};
+
+// Launches the kernel; cout_tiles in {1,2} (32 or 64 output channels).
+void launch_conv3x3(DType dt, int cout_tiles, ConvEpilogue epi, const ConvParams& p, hipStream_t stream);
+
+// Host-side weight packer: torch layout w[cout][cin][3][3] fp32 -> MFMA A-fragments.
+// Returns number of uint16 elements written (dst may be null to query).
+size_t pack_conv3x3_weights(DType dt, const float* w, int cout, int cin, int cout_tiles, int cin_chunks,
+                            uint16_t* dst);
+
+// ---- frame <-> tensor conversions -----------------------------------------------------------
+// uint8 BGR HxWx3 -> typed NHWC (32-channel padded), RGB order, /255.  unshuffle in {1,2}:
+// 2 = pixel_unshuffle(2) front end of the x2 model (12 channels), with reflect mod-padding to even size.
+void launch_u8_to_nhwc(DType dt, const uint8_t* in_bgr, int H, int W, void* out, int out_cstride,
+                       int unshuffle, hipStream_t stream);
+
+uint16_t f32_to_operand(DType dt, float f);
+float operand_to_f32(DType dt, uint16_t v);
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define FW_HIP_CHECK(expr)                                                                        \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            int _code = (_e == hipErrorOutOfMemory) ? 2 : 3;                                      \
+            throw fw::Error(_code, std::string(_e == hipErrorOutOfMemory ? "GPU out of memory: " : \
+                                                                           "HIP error: ") +       \
+                                       hipGetErrorString(_e) + " at " + __FILE__ + ":" +          \
+                                       std::to_string(__LINE__));                                 \
+        }                                                                                         \
+    } while (0)
+
+}  // namespace fw

@@ -1,0 +1,551 @@
+// RRDBNet (Real-ESRGAN generator) forward on one MI355X: launch sequencing, workspace and weights.
+//
+// Architecture: basicsr RRDBNet as constructed by the reference at
+// src/framewright/processors/pytorch_realesrgan.py:103-129; block arithmetic as spelled out in-tree at
+// src/framewright/processors/aesrgan_face.py:171-204 (ResidualDenseBlock, RRDB) and :249-269 (trunk + tail).
+// Data layout: the torch.cat([x, x1, x2, x3, x4]) of a residual dense block is never
+// materialised by copying — each RDB owns a 192-channel NHWC "concat" buffer, conv k reads its first
+// 64+32(k-1) channels and writes its 32 outputs into the next channel slice.  The residual trunk
+// (x5*0.2 + x, and the RRDB-level *0.2 + x) is carried in fp32 side buffers so operand rounding does not
+// accumulate over the 69 blocks.
+#include <mutex>
+#include <vector>
+#include <memory>
+#include <cstdio>
+#include "fw_internal.h"
+#include "../../include/framewright_hip.h"
+
+namespace fw {
+
+struct ConvLayer {
+    int cout = 0, cin = 0, ct = 0, chunks = 0;
+    void* d_w = nullptr;
+    float* d_b = nullptr;
+    bool set = false;
+};
+
+struct Workspace {
+    char* base = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace fw
+
+using namespace fw;
+
+struct fw_rrdbnet {
+    int device = 0;
+    int num_block = 0;
+    int scale = 4;
+    DType dt = DT_BF16;
+    std::mutex mu;
+    ConvLayer conv_first, conv_body, conv_up1, conv_up2, conv_hr, conv_last;
+    std::vector<ConvLayer> body;  // [num_block][3][5]
+    Workspace ws;
+    // profiling
+    bool profile = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    double prof_flops = 0;
+    hipStream_t prof_stream = nullptr;
+};
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+template <typename F>
+int guarded(F&& f) {
+    try {
+        f();
+        return FW_OK;
+    } catch (const fw::Error& e) {
+        return fail(e.code, e.what());
+    } catch (const std::bad_alloc&) {
+        return fail(FW_ERR_OOM, "host out of memory");
+    } catch (const std::exception& e) {
+        return fail(FW_ERR_INTERNAL, e.what());
+    }
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        FW_HIP_CHECK(hipGetDevice(&prev));
+        if (prev != dev) FW_HIP_CHECK(hipSetDevice(dev));
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Trunk (low-resolution) size for an H x W input.
+void trunk_size(const fw_rrdbnet* n, int H, int W, int* Ht, int* Wt) {
+    if (n->scale == 2) {
+        *Ht = (H + 1) / 2;
+        *Wt = (W + 1) / 2;
+    } else {
+        *Ht = H;
+        *Wt = W;
+    }
+}
+
+struct Plan {
+    size_t in_u8, out_u8, in32, cat0, cat1, F, R, tA, tB, U1, U2, U3, total;
+};
+
+Plan make_plan(const fw_rrdbnet* n, int H, int W) {
+    int Ht, Wt;
+    trunk_size(n, H, W, &Ht, &Wt);
+    const size_t px = (size_t)Ht * Wt;
+    const size_t s = (size_t)n->scale;
+    Plan p{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = o;
+        o += align_up(bytes, 256);
+        return at;
+    };
+    p.in_u8 = take((size_t)H * W * 3);
+    p.out_u8 = take((size_t)H * W * 3 * s * s);
+    p.in32 = take(px * 32 * 2);
+    p.cat0 = take(px * 192 * 2);
+    p.cat1 = take(px * 192 * 2);
+    p.F = take(px * 64 * 4);
+    p.R = take(px * 64 * 4);
+    p.tA = take(px * 64 * 4);
+    p.tB = take(px * 64 * 4);
+    p.U1 = take(px * 4 * 64 * 2);
+    p.U2 = take(px * 16 * 64 * 2);
+    p.U3 = take(px * 16 * 64 * 2);
+    p.total = o;
+    return p;
+}
+
+ConvLayer* find_layer(fw_rrdbnet* n, const std::string& key, int* want_cout, int* want_cin) {
+    const int in_ch = n->scale == 2 ? 12 : 3;
+    auto ret = [&](ConvLayer* l, int co, int ci) {
+        *want_cout = co;
+        *want_cin = ci;
+        return l;
+    };
+    if (key == "conv_first") return ret(&n->conv_first, 64, in_ch);
+    if (key == "conv_body") return ret(&n->conv_body, 64, 64);
+    if (key == "conv_up1") return ret(&n->conv_up1, 64, 64);
+    if (key == "conv_up2") return ret(&n->conv_up2, 64, 64);
+    if (key == "conv_hr") return ret(&n->conv_hr, 64, 64);
+    if (key == "conv_last") return ret(&n->conv_last, 3, 64);
+    int b = -1, r = -1, c = -1;
+    char tail = 0;
+    if (sscanf(key.c_str(), "body.%d.rdb%d.conv%d%c", &b, &r, &c, &tail) == 3 && b >= 0 && b < n->num_block && r >= 1 &&
+        r <= 3 && c >= 1 && c <= 5) {
+        ConvLayer* l = &n->body[((size_t)b * 3 + (r - 1)) * 5 + (c - 1)];
+        return ret(l, c == 5 ? 64 : 32, 64 + 32 * (c - 1));
+    }
+    return nullptr;
+}
+
+void free_layer(ConvLayer& l) {
+    if (l.d_w) (void)hipFree(l.d_w);
+    if (l.d_b) (void)hipFree(l.d_b);
+    l.d_w = nullptr;
+    l.d_b = nullptr;
+    l.set = false;
+}
+
+double conv_flops(const ConvLayer& l, size_t pixels) { return 2.0 * 9.0 * l.cin * l.cout * (double)pixels; }
+
+void run_conv(fw_rrdbnet* n, const ConvLayer& l, ConvEpilogue epi, ConvParams p, hipStream_t st) {
+    p.cin_chunks = l.chunks;
+    p.wpk = l.d_w;
+    p.bias = l.d_b;
+    if (n->profile) {
+        if (n->ev_used + 2 > n->ev_pool.size()) {
+            size_t old = n->ev_pool.size();
+            n->ev_pool.resize(old + 1024);
+            for (size_t i = old; i < n->ev_pool.size(); ++i) FW_HIP_CHECK(hipEventCreate(&n->ev_pool[i]));
+        }
+        FW_HIP_CHECK(hipEventRecord(n->ev_pool[n->ev_used++], st));
+        launch_conv3x3(n->dt, l.ct, epi, p, st);
+        FW_HIP_CHECK(hipEventRecord(n->ev_pool[n->ev_used++], st));
+        n->prof_flops += conv_flops(l, (size_t)p.H * p.W);
+        n->prof_stream = st;
+    } else {
+        launch_conv3x3(n->dt, l.ct, epi, p, st);
+    }
+}
+
+void forward(fw_rrdbnet* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, float* d_rgb, hipStream_t st) {
+    int Ht, Wt;
+    trunk_size(n, H, W, &Ht, &Wt);
+    const Plan pl = make_plan(n, H, W);
+    char* ws = n->ws.base;
+    void* in32 = ws + pl.in32;
+    void* cat[2] = {ws + pl.cat0, ws + pl.cat1};
+    float* F = (float*)(ws + pl.F);
+    float* R = (float*)(ws + pl.R);
+    float* tA = (float*)(ws + pl.tA);
+    float* tB = (float*)(ws + pl.tB);
+    void* U1 = ws + pl.U1;
+    void* U2 = ws + pl.U2;
+    void* U3 = ws + pl.U3;
+
+    launch_u8_to_nhwc(n->dt, d_in, H, W, in32, 32, n->scale == 2 ? 2 : 1, st);
+
+    ConvParams base{};
+    base.H = Ht;
+    base.W = Wt;
+    base.s1 = 1.f;
+    base.s2 = 1.f;
+
+    // conv_first -> concat buffer 0 [0:64] + fp32 trunk F          (aesrgan_face.py:250)
+    {
+        ConvParams p = base;
+        p.in = in32;
+        p.in_cstride = 32;
+        p.out = cat[0];
+        p.out_cstride = 192;
+        p.out_coff = 0;
+        p.out_f32 = F;
+        run_conv(n, n->conv_first, EPI_STORE, p, st);
+    }
+
+    int cur = 0;
+    for (int b = 0; b < n->num_block; ++b) {
+        const float* Rin = (b == 0) ? F : R;
+        for (int k = 0; k < 3; ++k) {
+            const ConvLayer* L = &n->body[((size_t)b * 3 + k) * 5];
+            // conv1..conv4: growth channels, LeakyReLU(0.2), written into the next slice    (:184-187)
+            for (int c = 0; c < 4; ++c) {
+                ConvParams p = base;
+                p.in = cat[cur];
+                p.in_cstride = 192;
+                p.out = cat[cur];
+                p.out_cstride = 192;
+                p.out_coff = 64 + 32 * c;
+                p.act = 1;
+                run_conv(n, L[c], EPI_STORE, p, st);
+            }
+            // conv5 + residual(s): x5*0.2 + x  (:188-189); after rdb3 additionally *0.2 + rrdb_in (:204)
+            ConvParams p = base;
+            p.in = cat[cur];
+            p.in_cstride = 192;
+            p.out = cat[cur ^ 1];
+            p.out_cstride = 192;
+            p.out_coff = 0;
+            p.s1 = 0.2f;
+            p.res1 = (k == 0) ? Rin : (k == 1 ? tA : tB);
+            if (k == 2) {
+                p.res2 = Rin;
+                p.s2 = 0.2f;
+                p.out_f32 = R;
+            } else {
+                p.out_f32 = (k == 0) ? tA : tB;
+            }
+            run_conv(n, L[4], EPI_RESIDUAL, p, st);
+            cur ^= 1;
+        }
+    }
+
+    // feat + conv_body(body_feat)                                                  (:256-257)
+    {
+        ConvParams p = base;
+        p.in = cat[cur];
+        p.in_cstride = 192;
+        p.out = cat[cur ^ 1];
+        p.out_cstride = 192;
+        p.out_coff = 0;
+        p.res1 = F;
+        p.s1 = 1.f;
+        run_conv(n, n->conv_body, EPI_RESIDUAL, p, st);
+        cur ^= 1;
+    }
+    // lrelu(conv_up1(nearest x2)), lrelu(conv_up2(nearest x2))                    (:260-266)
+    {
+        ConvParams p = base;
+        p.H = 2 * Ht;
+        p.W = 2 * Wt;
+        p.in = cat[cur];
+        p.in_cstride = 192;
+        p.upsample2x = 1;
+        p.out = U1;
+        p.out_cstride = 64;
+        p.act = 1;
+        run_conv(n, n->conv_up1, EPI_STORE, p, st);
+    }
+    {
+        ConvParams p = base;
+        p.H = 4 * Ht;
+        p.W = 4 * Wt;
+        p.in = U1;
+        p.in_cstride = 64;
+        p.upsample2x = 1;
+        p.out = U2;
+        p.out_cstride = 64;
+        p.act = 1;
+        run_conv(n, n->conv_up2, EPI_STORE, p, st);
+    }
+    // conv_last(lrelu(conv_hr(feat)))                                              (:268)
+    {
+        ConvParams p = base;
+        p.H = 4 * Ht;
+        p.W = 4 * Wt;
+        p.in = U2;
+        p.in_cstride = 64;
+        p.out = U3;
+        p.out_cstride = 64;
+        p.act = 1;
+        run_conv(n, n->conv_hr, EPI_STORE, p, st);
+    }
+    {
+        ConvParams p = base;
+        p.H = 4 * Ht;
+        p.W = 4 * Wt;
+        p.in = U3;
+        p.in_cstride = 64;
+        p.out_u8 = d_out;
+        p.out_rgb = d_rgb;
+        p.img_H = n->scale * H;  // crops the mod-pad of the x2 model
+        p.img_W = n->scale * W;
+        run_conv(n, n->conv_last, EPI_IMAGE, p, st);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fw_last_error(void) { return g_last_error.c_str(); }
+
+int fw_abi_version(void) { return 1; }
+
+int fw_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int fw_rrdbnet_create(int device_id, int num_block, int scale, int dtype, fw_rrdbnet** out) {
+    if (!out) return fail(FW_ERR_INVALID, "fw_rrdbnet_create: out is NULL");
+    *out = nullptr;
+    if (num_block < 1 || num_block > 64) return fail(FW_ERR_INVALID, "fw_rrdbnet_create: num_block out of range");
+    if (scale != 2 && scale != 4) return fail(FW_ERR_INVALID, "fw_rrdbnet_create: scale must be 2 or 4");
+    if (dtype != FW_DTYPE_BF16 && dtype != FW_DTYPE_F16) return fail(FW_ERR_INVALID, "fw_rrdbnet_create: bad dtype");
+    return guarded([&] {
+        int ndev = 0;
+        FW_HIP_CHECK(hipGetDeviceCount(&ndev));
+        if (device_id < 0 || device_id >= ndev) throw Error(FW_ERR_INVALID, "fw_rrdbnet_create: no such device");
+        auto n = std::make_unique<fw_rrdbnet>();
+        n->device = device_id;
+        n->num_block = num_block;
+        n->scale = scale;
+        n->dt = (DType)dtype;
+        n->body.resize((size_t)num_block * 15);
+        *out = n.release();
+    });
+}
+
+int fw_rrdbnet_set_conv(fw_rrdbnet* n, const char* key, const float* weight, const float* bias, int cout, int cin) {
+    if (!n || !key || !weight || !bias) return fail(FW_ERR_INVALID, "fw_rrdbnet_set_conv: NULL argument");
+    return guarded([&] {
+        std::lock_guard<std::mutex> lk(n->mu);
+        int wco = 0, wci = 0;
+        ConvLayer* l = find_layer(n, key, &wco, &wci);
+        if (!l) throw Error(FW_ERR_INVALID, std::string("fw_rrdbnet_set_conv: unknown key '") + key + "'");
+        if (cout != wco || cin != wci)
+            throw Error(FW_ERR_INVALID, std::string("fw_rrdbnet_set_conv: shape mismatch for '") + key + "': got [" +
+                                            std::to_string(cout) + "," + std::to_string(cin) + ",3,3], expected [" +
+                                            std::to_string(wco) + "," + std::to_string(wci) + ",3,3]");
+        DeviceGuard dg(n->device);
+        free_layer(*l);
+        l->cout = cout;
+        l->cin = cin;
+        l->ct = (cout + 31) / 32;
+        l->chunks = (cin + 31) / 32;
+        const size_t ne = pack_conv3x3_weights(n->dt, nullptr, cout, cin, l->ct, l->chunks, nullptr);
+        std::vector<uint16_t> packed(ne);
+        pack_conv3x3_weights(n->dt, weight, cout, cin, l->ct, l->chunks, packed.data());
+        std::vector<float> b(32 * l->ct, 0.f);
+        for (int i = 0; i < cout; ++i) b[i] = bias[i];
+        FW_HIP_CHECK(hipMalloc(&l->d_w, ne * 2));
+        FW_HIP_CHECK(hipMalloc((void**)&l->d_b, b.size() * 4));
+        FW_HIP_CHECK(hipMemcpy(l->d_w, packed.data(), ne * 2, hipMemcpyHostToDevice));
+        FW_HIP_CHECK(hipMemcpy(l->d_b, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+        l->set = true;
+    });
+}
+
+int fw_rrdbnet_finalize(fw_rrdbnet* n) {
+    if (!n) return fail(FW_ERR_INVALID, "fw_rrdbnet_finalize: NULL");
+    std::lock_guard<std::mutex> lk(n->mu);
+    const ConvLayer* singles[] = {&n->conv_first, &n->conv_body, &n->conv_up1, &n->conv_up2, &n->conv_hr, &n->conv_last};
+    const char* names[] = {"conv_first", "conv_body", "conv_up1", "conv_up2", "conv_hr", "conv_last"};
+    for (int i = 0; i < 6; ++i)
+        if (!singles[i]->set) return fail(FW_ERR_INVALID, std::string("fw_rrdbnet_finalize: missing ") + names[i]);
+    for (size_t i = 0; i < n->body.size(); ++i)
+        if (!n->body[i].set)
+            return fail(FW_ERR_INVALID, "fw_rrdbnet_finalize: missing body." + std::to_string(i / 15) + ".rdb" +
+                                            std::to_string((i / 5) % 3 + 1) + ".conv" + std::to_string(i % 5 + 1));
+    return FW_OK;
+}
+
+size_t fw_rrdbnet_workspace_bytes(const fw_rrdbnet* n, int H, int W) {
+    if (!n || H < 1 || W < 1) return 0;
+    return make_plan(n, H, W).total;
+}
+
+double fw_rrdbnet_flops(const fw_rrdbnet* n, int H, int W) {
+    if (!n || H < 1 || W < 1) return 0.0;
+    int Ht, Wt;
+    trunk_size(n, H, W, &Ht, &Wt);
+    const double px = (double)Ht * Wt;
+    const double in_ch = n->scale == 2 ? 12 : 3;
+    double mac = 9.0 * in_ch * 64;                                             // conv_first
+    mac += n->num_block * 3.0 * 9.0 * (64 * 32 + 96 * 32 + 128 * 32 + 160 * 32 + 192 * 64);  // RRDB trunk
+    mac += 9.0 * 64 * 64;                                                      // conv_body
+    mac += 9.0 * 64 * 64 * 4;                                                  // conv_up1 at 2x
+    mac += 9.0 * 64 * 64 * 16 * 2;                                             // conv_up2, conv_hr at 4x
+    mac += 9.0 * 64 * 3 * 16;                                                  // conv_last
+    return 2.0 * mac * px;
+}
+
+int fw_rrdbnet_upscale_u8(fw_rrdbnet* n, const uint8_t* in_bgr, int in_loc, int H, int W, uint8_t* out_bgr,
+                          int out_loc, float* out_rgb_f32, void* stream) {
+    if (!n || !in_bgr) return fail(FW_ERR_INVALID, "fw_rrdbnet_upscale_u8: NULL argument");
+    if (!out_bgr && !out_rgb_f32) return fail(FW_ERR_INVALID, "fw_rrdbnet_upscale_u8: no output requested");
+    if (H < 1 || W < 1 || H > 16384 || W > 16384) return fail(FW_ERR_INVALID, "fw_rrdbnet_upscale_u8: bad frame size");
+    if (n->scale == 2 && (H < 2 || W < 2)) return fail(FW_ERR_INVALID, "fw_rrdbnet_upscale_u8: x2 needs >= 2x2 input");
+    if ((in_loc != FW_HOST && in_loc != FW_DEVICE) || (out_loc != FW_HOST && out_loc != FW_DEVICE))
+        return fail(FW_ERR_INVALID, "fw_rrdbnet_upscale_u8: bad buffer location");
+    int rc = fw_rrdbnet_finalize(n);
+    if (rc != FW_OK) return rc;
+    return guarded([&] {
+        std::lock_guard<std::mutex> lk(n->mu);
+        DeviceGuard dg(n->device);
+        hipStream_t st = (hipStream_t)stream;
+        const Plan pl = make_plan(n, H, W);
+        if (n->ws.bytes < pl.total) {
+            // the previous workspace may still be in use by work queued on some stream
+            FW_HIP_CHECK(hipDeviceSynchronize());
+            if (n->ws.base) (void)hipFree(n->ws.base);
+            n->ws.base = nullptr;
+            n->ws.bytes = 0;
+            FW_HIP_CHECK(hipMalloc((void**)&n->ws.base, pl.total));
+            n->ws.bytes = pl.total;
+        }
+        const size_t in_bytes = (size_t)H * W * 3;
+        const size_t out_bytes = in_bytes * n->scale * n->scale;
+        const uint8_t* d_in = in_bgr;
+        if (in_loc == FW_HOST) {
+            uint8_t* stage = (uint8_t*)(n->ws.base + pl.in_u8);
+            FW_HIP_CHECK(hipMemcpyAsync(stage, in_bgr, in_bytes, hipMemcpyHostToDevice, st));
+            d_in = stage;
+        }
+        uint8_t* d_out = out_bgr;
+        if (out_bgr && out_loc == FW_HOST) d_out = (uint8_t*)(n->ws.base + pl.out_u8);
+        forward(n, d_in, H, W, d_out, out_rgb_f32, st);
+        if (out_bgr && out_loc == FW_HOST) {
+            FW_HIP_CHECK(hipMemcpyAsync(out_bgr, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+            FW_HIP_CHECK(hipStreamSynchronize(st));
+        }
+    });
+}
+
+int fw_rrdbnet_profile_enable(fw_rrdbnet* n, int on) {
+    if (!n) return fail(FW_ERR_INVALID, "fw_rrdbnet_profile_enable: NULL");
+    std::lock_guard<std::mutex> lk(n->mu);
+    n->profile = on != 0;
+    n->ev_used = 0;
+    n->prof_flops = 0;
+    return FW_OK;
+}
+
+int fw_rrdbnet_profile_read(fw_rrdbnet* n, int* launches, double* total_ms, double* total_flops) {
+    if (!n) return fail(FW_ERR_INVALID, "fw_rrdbnet_profile_read: NULL");
+    return guarded([&] {
+        std::lock_guard<std::mutex> lk(n->mu);
+        DeviceGuard dg(n->device);
+        double ms = 0;
+        if (n->ev_used) FW_HIP_CHECK(hipEventSynchronize(n->ev_pool[n->ev_used - 1]));
+        for (size_t i = 0; i + 1 < n->ev_used; i += 2) {
+            float t = 0;
+            FW_HIP_CHECK(hipEventElapsedTime(&t, n->ev_pool[i], n->ev_pool[i + 1]));
+            ms += t;
+        }
+        if (launches) *launches = (int)(n->ev_used / 2);
+        if (total_ms) *total_ms = ms;
+        if (total_flops) *total_flops = n->prof_flops;
+        n->ev_used = 0;
+        n->prof_flops = 0;
+    });
+}
+
+int fw_rrdbnet_destroy(fw_rrdbnet* n) {
+    if (!n) return FW_OK;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(n->device);
+    (void)hipDeviceSynchronize();
+    for (auto& l : n->body) free_layer(l);
+    free_layer(n->conv_first);
+    free_layer(n->conv_body);
+    free_layer(n->conv_up1);
+    free_layer(n->conv_up2);
+    free_layer(n->conv_hr);
+    free_layer(n->conv_last);
+    if (n->ws.base) (void)hipFree(n->ws.base);
+    for (auto e : n->ev_pool) (void)hipEventDestroy(e);
+    if (prev >= 0) (void)hipSetDevice(prev);
+    delete n;
+    return FW_OK;
+}
+
+size_t fw_pack_conv3x3(int dtype, const float* weight, int cout, int cin, int cout_tiles, int cin_chunks,
+                       uint16_t* dst) {
+    if (cout < 1 || cin < 1 || cout_tiles < 1 || cin_chunks < 1 || cout > 32 * cout_tiles || cin > 32 * cin_chunks)
+        return 0;
+    if (dst && !weight) return 0;
+    return pack_conv3x3_weights((DType)dtype, weight, cout, cin, cout_tiles, cin_chunks, dst);
+}
+
+int fw_conv3x3_nhwc(int dtype, const void* x, int in_cstride, int cin_chunks, int H, int W, const void* packed_weight,
+                    const float* bias, int cout_tiles, int act_lrelu, int upsample2x, const float* res1, float s1,
+                    const float* res2, float s2, void* out, int out_cstride, int out_coff, float* out_f32,
+                    void* stream) {
+    if (!x || !packed_weight || !bias) return fail(FW_ERR_INVALID, "fw_conv3x3_nhwc: NULL argument");
+    if (dtype != FW_DTYPE_BF16 && dtype != FW_DTYPE_F16) return fail(FW_ERR_INVALID, "fw_conv3x3_nhwc: bad dtype");
+    if (cout_tiles != 1 && cout_tiles != 2) return fail(FW_ERR_INVALID, "fw_conv3x3_nhwc: cout_tiles must be 1 or 2");
+    if (res1 && cout_tiles != 2) return fail(FW_ERR_INVALID, "fw_conv3x3_nhwc: residual epilogue needs 64 channels");
+    if (!res1 && res2) return fail(FW_ERR_INVALID, "fw_conv3x3_nhwc: res2 without res1");
+    return guarded([&] {
+        ConvParams p{};
+        p.in = x;
+        p.in_cstride = in_cstride;
+        p.cin_chunks = cin_chunks;
+        p.H = H;
+        p.W = W;
+        p.wpk = packed_weight;
+        p.bias = bias;
+        p.out = out;
+        p.out_cstride = out_cstride;
+        p.out_coff = out_coff;
+        p.out_f32 = out_f32;
+        p.res1 = res1;
+        p.res2 = res2;
+        p.s1 = s1;
+        p.s2 = s2;
+        p.act = act_lrelu;
+        p.upsample2x = upsample2x;
+        launch_conv3x3((DType)dtype, cout_tiles, res1 ? EPI_RESIDUAL : EPI_STORE, p, (hipStream_t)stream);
+    });
+}
+
+}  // extern "C"

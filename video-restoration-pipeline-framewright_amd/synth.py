@@ -1,0 +1,97 @@
+"""Synthetic weights and clips (there is no network access for checkpoints or datasets).
+
+The recipes are the ones fixed in SURVEY.md §8d so that tests, bench.py and the golden fixtures all see the
+same numbers:
+
+* weights: ``numpy.random.default_rng(seed)`` (PCG64 — stream stable across numpy versions), PyTorch's
+  default Conv2d initialisation restated (U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and bias), every
+  ``conv5`` multiplied by 0.1 so the 23-block trunk stays O(1), and ``conv_last`` rescaled so that the network
+  output occupies the [0,1] image range like a trained generator's (tolerances in the tests are stated on that
+  range).  Keys/shapes are BasicSR's RRDBNet state-dict (reference call site
+  src/framewright/processors/pytorch_realesrgan.py:107-127).
+* clips: smooth moving content (6 random 2-D sinusoids + 32 random rectangles, translated per frame) plus
+  N(0, 4) noise, uint8 BGR.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterator, List, Tuple
+
+import numpy as np
+
+RRDB_MODELS = {
+    # name -> (num_block, netscale)  — pytorch_realesrgan.py:103-129
+    "RealESRGAN_x4plus": (23, 4),
+    "RealESRGAN_x4plus_anime_6B": (6, 4),
+    "RealESRGAN_x2plus": (23, 2),
+    # the reference declares these two as RRDBNet as well (SURVEY.md §8f lists that as a reference defect;
+    # the declared architecture is what get_upsampler() would build, so it is what is built here)
+    "realesr-animevideov3": (6, 4),
+    "realesr-general-x4v3": (23, 4),
+}
+
+
+def rrdbnet_conv_shapes(num_block: int, scale: int, num_feat: int = 64, grow: int = 32) -> List[Tuple[str, int, int]]:
+    """[(key, cout, cin)] in forward order."""
+    in_ch = 3 * (4 if scale == 2 else 1)
+    shapes = [("conv_first", num_feat, in_ch)]
+    for b in range(num_block):
+        for r in (1, 2, 3):
+            for c in range(1, 6):
+                shapes.append((f"body.{b}.rdb{r}.conv{c}", num_feat if c == 5 else grow, num_feat + grow * (c - 1)))
+    shapes += [("conv_body", num_feat, num_feat), ("conv_up1", num_feat, num_feat), ("conv_up2", num_feat, num_feat),
+               ("conv_hr", num_feat, num_feat), ("conv_last", 3, num_feat)]
+    return shapes
+
+
+def synthetic_rrdbnet_state(num_block: int, scale: int, seed: int = 1234, num_feat: int = 64, grow: int = 32,
+                            image_range: bool = True) -> Dict[str, np.ndarray]:
+    """Seeded state-dict (numpy fp32 arrays) with BasicSR key names."""
+    rng = np.random.default_rng(seed)
+    sd: Dict[str, np.ndarray] = {}
+    for key, cout, cin in rrdbnet_conv_shapes(num_block, scale, num_feat, grow):
+        bound = 1.0 / np.sqrt(cin * 9)
+        w = rng.uniform(-bound, bound, size=(cout, cin, 3, 3)).astype(np.float32)
+        b = rng.uniform(-bound, bound, size=(cout,)).astype(np.float32)
+        if key.endswith(".conv5"):
+            w *= np.float32(0.1)
+            b *= np.float32(0.1)
+        if key == "conv_last" and image_range:
+            w *= np.float32(0.25)
+            b = b * np.float32(0.25) + np.float32(0.5)
+        sd[key + ".weight"] = w
+        sd[key + ".bias"] = b
+    return sd
+
+
+def synthetic_clip(num_frames: int, height: int, width: int, seed: int) -> Iterator[np.ndarray]:
+    """Yields ``num_frames`` uint8 BGR frames (H x W x 3) of smooth moving content + noise."""
+    rng = np.random.default_rng(seed)
+    freqs = rng.uniform(0.5, 6.0, size=(6, 2)) * 2 * np.pi
+    phases = rng.uniform(0, 2 * np.pi, size=(6, 3))
+    amps = rng.uniform(8.0, 28.0, size=(6, 3))
+    rects = rng.uniform(0, 1, size=(32, 4))
+    rect_col = rng.uniform(-60, 60, size=(32, 3))
+    vx, vy = rng.uniform(-3, 3, size=2)
+    yy, xx = np.meshgrid(np.arange(height, dtype=np.float32), np.arange(width, dtype=np.float32), indexing="ij")
+    for t in range(num_frames):
+        u = (xx + vx * t) / max(width, 1)
+        v = (yy + vy * t) / max(height, 1)
+        img = np.full((height, width, 3), 120.0, dtype=np.float32)
+        for k in range(6):
+            arg = freqs[k, 0] * u + freqs[k, 1] * v
+            for c in range(3):
+                img[:, :, c] += amps[k, c] * np.sin(arg + phases[k, c])
+        uf = u - np.floor(u)
+        vf = v - np.floor(v)
+        for k in range(32):
+            x0, y0 = rects[k, 0], rects[k, 1]
+            w = 0.02 + 0.15 * rects[k, 2]
+            h = 0.02 + 0.15 * rects[k, 3]
+            m = (uf >= x0) & (uf < x0 + w) & (vf >= y0) & (vf < y0 + h)
+            img[m] += rect_col[k]
+        img += rng.normal(0.0, 4.0, size=img.shape).astype(np.float32)
+        yield np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def synthetic_frames(num_frames: int, height: int, width: int, seed: int) -> np.ndarray:
+    return np.stack(list(synthetic_clip(num_frames, height, width, seed)))
