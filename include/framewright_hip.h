@@ -115,16 +115,20 @@ size_t fw_pack_conv3x3(int dtype, const float* weight, int cout, int cin, int co
                        uint16_t* dst);
 
 /* y = act(conv3x3(x) + bias) written to channels [out_coff, out_coff + 32*cout_tiles) of an NHWC operand-typed
- * buffer.  x: NHWC operand-typed, in_cstride channels per pixel, first 32*cin_chunks channels are contracted.
+ * buffer.  x: operand-typed; pixel (y,x) of 32-channel chunk c starts at element
+ * c*in_plane_stride + (y*W + x)*in_cstride.  in_plane_stride = 0 (or 32) is plain interleaved NHWC with in_cstride
+ * channels per pixel; in_plane_stride = H*W*in_cstride with in_cstride = 32 is the chunk-planar layout the RRDB
+ * trunk uses (every chunk read is a contiguous stream of whole cache lines).  The first 32*cin_chunks channels are
+ * contracted.  The two 32-channel halves of a 64-channel output are out_plane_stride elements apart (0 = 32).
  * upsample2x = 1: x is (H/2 x W/2) and is nearest-neighbour upsampled on the fly (conv_up1/conv_up2 of
  * aesrgan_face.py:258-266).  res1/res2 (fp32 NHWC, 32*cout_tiles channels, may be NULL):
  *   res1 == NULL:  y = act(acc + bias)
  *   res1 != NULL:  y = (acc + bias) * s1 + res1; if res2: y = y * s2 + res2     (aesrgan_face.py:189,204)
  * out / out_f32 may each be NULL. */
-int fw_conv3x3_nhwc(int dtype, const void* x, int in_cstride, int cin_chunks, int height, int width,
-                    const void* packed_weight, const float* bias, int cout_tiles, int act_lrelu, int upsample2x,
-                    const float* res1, float s1, const float* res2, float s2, void* out, int out_cstride,
-                    int out_coff, float* out_f32, void* stream);
+int fw_conv3x3_nhwc(int dtype, const void* x, int in_cstride, long in_plane_stride, int cin_chunks, int height,
+                    int width, const void* packed_weight, const float* bias, int cout_tiles, int act_lrelu,
+                    int upsample2x, const float* res1, float s1, const float* res2, float s2, void* out,
+                    int out_cstride, long out_plane_stride, int out_coff, float* out_f32, void* stream);
 
 #ifdef __cplusplus
 }

@@ -35,8 +35,8 @@ def _run(lib, dtype, x_nhwc, cin, w, b, H, W, act=0, ups=0, res1=None, s1=1.0, r
     out = torch.full((H, W, out_cstride), 7.0, dtype=TDT[dtype], device="cuda")
     out_f32 = torch.zeros((H, W, 32 * ct), dtype=torch.float32, device="cuda") if want_f32 else None
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-    st = lib.fw_conv3x3_nhwc(dtype, p(x_nhwc), x_nhwc.shape[-1], ch, H, W, p(wp), p(bias), ct, act, ups,
-                             p(res1), s1, p(res2), s2, p(out), out_cstride, out_coff, p(out_f32),
+    st = lib.fw_conv3x3_nhwc(dtype, p(x_nhwc), x_nhwc.shape[-1], 0, ch, H, W, p(wp), p(bias), ct, act, ups,
+                             p(res1), s1, p(res2), s2, p(out), out_cstride, 0, out_coff, p(out_f32),
                              C.c_void_p(torch.cuda.current_stream().cuda_stream))
     _lib.check(st)
     torch.cuda.synchronize()
@@ -104,8 +104,8 @@ def test_conv_in_place_concat_buffer(hip_lib, dtype):
     wp = _pack(hip_lib, dtype, w, 1, 2)
     bias = torch.from_numpy(b).cuda()
     p = lambda t: C.c_void_p(t.data_ptr())
-    _lib.check(hip_lib.fw_conv3x3_nhwc(dtype, p(buf), 192, 2, H, W, p(wp), p(bias), 1, 1, 0, None, 1.0, None, 1.0,
-                                       p(buf), 192, 64, None, None))
+    _lib.check(hip_lib.fw_conv3x3_nhwc(dtype, p(buf), 192, 0, 2, H, W, p(wp), p(bias), 1, 1, 0, None, 1.0, None, 1.0,
+                                       p(buf), 192, 0, 64, None, None))
     torch.cuda.synchronize()
     assert torch.equal(buf[..., :64], keep[..., :64]) and torch.equal(buf[..., 96:], keep[..., 96:])
     assert (buf[..., 64:96].float() - ref).abs().max().item() < (2e-2 if dtype == _lib.FW_DTYPE_BF16 else 3e-3)
@@ -145,9 +145,30 @@ def test_conv_residual_epilogue(hip_lib, dtype, two):
 def test_conv_rejects_bad_arguments(hip_lib):
     x = torch.zeros((4, 4, 64), dtype=torch.bfloat16, device="cuda")
     p = C.c_void_p(x.data_ptr())
-    assert hip_lib.fw_conv3x3_nhwc(0, p, 64, 3, 4, 4, p, p, 1, 0, 0, None, 1.0, None, 1.0, p, 32, 0, None, None) \
+    assert hip_lib.fw_conv3x3_nhwc(0, p, 64, 0, 3, 4, 4, p, p, 1, 0, 0, None, 1.0, None, 1.0, p, 32, 0, 0, None, None) \
         == _lib.FW_ERR_INVALID            # contracts 96 channels of a 64-channel buffer
-    assert hip_lib.fw_conv3x3_nhwc(0, p, 64, 2, 5, 4, p, p, 1, 0, 1, None, 1.0, None, 1.0, p, 32, 0, None, None) \
+    assert hip_lib.fw_conv3x3_nhwc(0, p, 64, 0, 2, 5, 4, p, p, 1, 0, 1, None, 1.0, None, 1.0, p, 32, 0, 0, None, None) \
         == _lib.FW_ERR_INVALID            # upsample needs even output
-    assert hip_lib.fw_conv3x3_nhwc(0, p, 64, 2, 4, 4, p, p, 3, 0, 0, None, 1.0, None, 1.0, p, 32, 0, None, None) \
+    assert hip_lib.fw_conv3x3_nhwc(0, p, 64, 0, 2, 4, 4, p, p, 3, 0, 0, None, 1.0, None, 1.0, p, 32, 0, 0, None, None) \
         == _lib.FW_ERR_INVALID
+
+
+@pytest.mark.parametrize("dtype", [_lib.FW_DTYPE_BF16, _lib.FW_DTYPE_F16])
+def test_conv_chunk_planar_layout(hip_lib, dtype):
+    """The layout the RRDB trunk uses: 32-channel planes [chunk][H][W][32] in, two planes out."""
+    rng = np.random.default_rng(5)
+    H, W, cin = 27, 43, 160
+    x = torch.from_numpy(rng.standard_normal((H, W, cin)).astype(np.float32)).cuda().to(TDT[dtype])
+    planes = x.reshape(H, W, cin // 32, 32).permute(2, 0, 1, 3).contiguous()       # [5][H][W][32]
+    w = (rng.standard_normal((64, cin, 3, 3)) / 38).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    wp = _pack(hip_lib, dtype, w, 2, 5)
+    bias = torch.from_numpy(b).cuda()
+    out = torch.zeros((2, H, W, 32), dtype=TDT[dtype], device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(hip_lib.fw_conv3x3_nhwc(dtype, p(planes), 32, H * W * 32, 5, H, W, p(wp), p(bias), 2, 1, 0, None, 1.0,
+                                       None, 1.0, p(out), 32, H * W * 32, 0, None, None))
+    torch.cuda.synchronize()
+    ref = _ref(dtype, x, cin, w, b, act=1)
+    got = out.permute(1, 2, 0, 3).reshape(H, W, 64).float()
+    assert (got - ref).abs().max().item() < (2e-2 if dtype == _lib.FW_DTYPE_BF16 else 3e-3)

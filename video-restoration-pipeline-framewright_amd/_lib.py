@@ -73,8 +73,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.fw_pack_conv3x3.restype = sz
     lib.fw_pack_conv3x3.argtypes = [i32, vp, i32, i32, i32, i32, vp]
     lib.fw_conv3x3_nhwc.restype = i32
-    lib.fw_conv3x3_nhwc.argtypes = [i32, vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp, f32, vp, f32, vp, i32,
-                                    i32, vp, vp]
+    lib.fw_conv3x3_nhwc.argtypes = [i32, vp, i32, C.c_long, i32, i32, i32, vp, vp, i32, i32, i32, vp, f32, vp, f32, vp,
+                                    i32, C.c_long, i32, vp, vp]
 
 
 def load() -> C.CDLL:

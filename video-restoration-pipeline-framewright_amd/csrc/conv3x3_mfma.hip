@@ -60,7 +60,8 @@ constexpr int TILE_H = 16;
 constexpr int TILE_W = 32;
 constexpr int HALO_H = TILE_H + 2;                        // 18
 constexpr int HALO_W = TILE_W + 2;                        // 34
-constexpr int ACT_PIECES = HALO_H * HALO_W * 4;           // 16-byte pieces per 32-channel chunk = 2448
+constexpr int ROW_PIECES = HALO_W * 4;                    // 136 16-byte pieces per halo row
+constexpr int ACT_PIECES = HALO_H * ROW_PIECES;           // 2448 pieces per 32-channel chunk
 constexpr int ACT_INSTR = (ACT_PIECES + 63) / 64;         // 39 wave-instructions of 1 KiB
 constexpr int ACT_REGION = ACT_INSTR * 64;                // 2496 pieces (tail of the last instruction unused)
 constexpr int ACT_ITERS = (ACT_INSTR + 3) / 4;            // 10 per wave
@@ -80,21 +81,31 @@ struct Smem {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-// One global_load_lds_dwordx4: every active lane copies 16 bytes from its own global address to
-// LDS[lds_dst + 16 * lane]; lds_dst must be wave-uniform.  M0 is written and restored inside the statement
-// (cdna_hip_programming.md §5.7).
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+// One global_load_lds_dwordx4: every active lane copies 16 bytes from (base + voff) to LDS[lds_dst + 16 * lane];
+// base and lds_dst are wave-uniform.  Inline asm so that hipcc does not count these loads: with the builtin it
+// drains them (s_waitcnt vmcnt(0)) before the first ds_read of the chunk being computed, which serialises the
+// pipeline (cdna_hip_programming.md §5 "Three .s-level traps" (b)).  The matching wait is the explicit vmcnt(0)
+// at the top of the chunk loop.  M0 is written and restored inside the statement (§5.7).
+__device__ __forceinline__ void glds16(const void* base, unsigned voff, unsigned lds_dst) {
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
+        "s_mov_b32 m0, %3\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst)
+        : "v"(voff), "s"(base), "s"(lds_dst)
         : "memory");
 }
+
+// Fragments of one (k-step, dx) group: the wave's 6 halo rows at column offset dx and the 3 (dy) weight
+// fragments per cout tile -> 12*CT MFMAs.
+template <int CT>
+struct Frags {
+    uint4 x[6];
+    uint4 w[3][CT];
+};
 
 template <typename T, int CT, int EPI>
 __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(const ConvParams p) {
@@ -102,193 +113,203 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(const ConvParams p
     constexpr int BUF = Smem<CT>::BUF;
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int r = lane & 31;
     const int h = lane >> 5;
 
-    // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so XCD g takes a contiguous band of
-    // tiles — neighbouring tiles share halo rows and every tile re-reads the same weights.  Bijective for any
-    // tile count (cdna_hip_programming.md §5 "XCD swizzle must be bijective").
-    const int ntiles = gridDim.x;
+    // ---- persistent workgroup: a contiguous range of tiles ---------------------------------------------------
+    // Blocks b and b+8 share an XCD (and its L2): logical id lb puts the blocks of one XCD on a contiguous band of
+    // tiles, so vertically neighbouring tiles (shared halo rows) and the weights are served by one L2.
+    const int NB = gridDim.x;
     const int xcd = blockIdx.x & 7;
-    const int q = ntiles >> 3, rem = ntiles & 7;
-    const int tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (blockIdx.x >> 3);
+    const int qn = NB >> 3, rn = NB & 7;
+    const int lb = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blockIdx.x >> 3);
     const int tiles_x = (p.W + TILE_W - 1) / TILE_W;
-    const int tile_y = tile / tiles_x;
-    const int tile_x = tile - tile_y * tiles_x;
-    const int y0 = tile_y * TILE_H;
-    const int x0 = tile_x * TILE_W;
+    const int ntiles = tiles_x * ((p.H + TILE_H - 1) / TILE_H);
+    const int t_lo = (int)((long)lb * ntiles / NB);
+    const int t_hi = (int)((long)(lb + 1) * ntiles / NB);
+    if (t_lo >= t_hi) return;
 
-    // ---- per-lane staging plan (chunk invariant) ---------------------------------------------------------
+    // ---- tile-invariant per-lane DMA plan -----------------------------------------------------------------------
     const int ups = p.upsample2x;
     const int Ws = ups ? (p.W >> 1) : p.W;
-    const T* in = reinterpret_cast<const T*>(p.in);
-    const T* src[ACT_ITERS];  // source of this lane's 8-channel piece in chunk 0 (nullptr: outside the image)
+    const long org = ((long)Ws + 1) * p.in_cstride;  // elements between the DMA base and the tile origin
+    unsigned rel[ACT_ITERS];                          // byte offset of this lane's piece from the DMA base
+    int rp[ACT_ITERS];                                // (halo row << 8) | halo px, or -1 for the unused tail
 #pragma unroll
     for (int i = 0; i < ACT_ITERS; ++i) {
         const int idx = (wave + 4 * i) * 64 + lane;
-        const int row = idx / (HALO_W * 4);
-        const int rm = idx - row * (HALO_W * 4);
+        const int row = idx / ROW_PIECES;
+        const int rm = idx - row * ROW_PIECES;
         const int px = rm >> 2;
         const int s = (rm & 3) ^ ((px >> 2) & 3);  // which 8-channel slot lands at this LDS position
-        const int gy = y0 - 1 + row;
-        const int gx = x0 - 1 + px;
-        const bool ok = (idx < ACT_PIECES) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        const int sy = ups ? (gy >> 1) : gy;
-        const int sx = ups ? (gx >> 1) : gx;
-        src[i] = ok ? in + ((size_t)sy * Ws + sx) * p.in_cstride + s * 8 : nullptr;
-        // zero padding: the DMA never writes these positions, so clear them once in both stages
-        if (!ok && idx < ACT_REGION) {
-            lds[idx] = make_uint4(0, 0, 0, 0);
-            lds[BUF + idx] = make_uint4(0, 0, 0, 0);
-        }
+        const int srow = ups ? ((row - 1) >> 1) : (row - 1);
+        const int spx = ups ? ((px - 1) >> 1) : (px - 1);
+        rel[i] = (unsigned)(((long)srow * Ws + spx) * p.in_cstride + s * 8 + org) * 2u;
+        rp[i] = (idx < ACT_PIECES) ? ((row << 8) | px) : -1;
     }
-    const uint4* wsrc = reinterpret_cast<const uint4*>(p.wpk) + lane;
-
-    // LDS-DMA issue.  Written as inline asm so that hipcc does not count these loads: with the builtin it drains
-    // them (s_waitcnt vmcnt(0)) before the first ds_read of the chunk being computed, which serialises the
-    // pipeline (cdna_hip_programming.md §5 "Three .s-level traps" (b)).  The matching wait is the explicit
-    // vmcnt(0) at the top of the chunk loop.
     const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)lds;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    auto stage = [&](int c, int buf) {
-        const unsigned dst = lds_base + (unsigned)(buf * BUF) * 16u;
+    const char* in_b = reinterpret_cast<const char*>(p.in);
+    const char* w_b = reinterpret_cast<const char*>(p.wpk);
+
+    // DMA of (tile origin ty0/tx0, chunk c) into pipeline stage `st`; positions outside the image are zeroed.
+    auto issue = [&](int ty0, int tx0, int c, int st) {
+        const int sy0 = ups ? (ty0 >> 1) : ty0;
+        const int sx0 = ups ? (tx0 >> 1) : tx0;
+        const char* base = in_b + (((long)sy0 * Ws + sx0) * p.in_cstride - org + c * p.in_pstride) * 2;
+        const unsigned dst = lds_base + (unsigned)(st * BUF) * 16u;
 #pragma unroll
         for (int i = 0; i < ACT_ITERS; ++i) {
-            const int j = wave_u + 4 * i;
-            if (j < ACT_INSTR && src[i]) glds16(src[i] + c * 32, dst + (unsigned)j * 1024u);
+            const int j = wave + 4 * i;
+            if (j < ACT_INSTR) {
+                const int gy = ty0 - 1 + (rp[i] >> 8);
+                const int gx = tx0 - 1 + (rp[i] & 255);
+                const bool ok = rp[i] >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+                if (ok)
+                    glds16(base, rel[i], dst + (unsigned)j * 1024u);
+                else if (rp[i] >= 0)
+                    lds[st * BUF + j * 64 + lane] = make_uint4(0, 0, 0, 0);
+            }
         }
-        const uint4* wc = wsrc + (size_t)c * (W_FRAGS * CT * 64);
+        const char* wc = w_b + (size_t)c * (W_FRAGS * CT * 1024);
 #pragma unroll
         for (int i = 0; i < (W_FRAGS * CT + 3) / 4; ++i) {
-            const int f = wave_u + 4 * i;
-            if (f < W_FRAGS * CT) glds16(wc + f * 64, dst + (unsigned)(ACT_REGION + f * 64) * 16u);
+            const int f = wave + 4 * i;
+            if (f < W_FRAGS * CT) glds16(wc + f * 1024, (unsigned)lane * 16u, dst + (unsigned)(ACT_REGION + f * 64) * 16u);
         }
     };
 
-    // ---- accumulators, initialised with the bias -------------------------------------------------------------
+    // ---- fragment-read plan ------------------------------------------------------------------------------------
+    int rd_off[3][2];  // [dx][ks]: piece index of (halo row 4*wave, px r+dx, k-step ks) for this lane
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            rd_off[dx][ks] = (4 * wave) * ROW_PIECES + (r + dx) * 4 + ((2 * ks + h) ^ (((r + dx) >> 2) & 3));
+
+    auto load_group = [&](Frags<CT>& f, const uint4* a, const uint4* wl, int g) {
+        const int ks = g / 3, dx = g - ks * 3;
+#pragma unroll
+        for (int row = 0; row < 6; ++row) f.x[row] = a[row * ROW_PIECES + rd_off[dx][ks]];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) f.w[dy][ct] = wl[(((dy * 3 + dx) * 2 + ks) * CT + ct) * 64];
+    };
+
     f32x16 acc[4][CT];
+    auto mfma_group = [&](const Frags<CT>& f) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        f32x16 b;
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) b[i] = p.bias[32 * ct + (i & 3) + 8 * (i >> 2) + 4 * h];
+            for (int row = 0; row < 4; ++row)
 #pragma unroll
-        for (int row = 0; row < 4; ++row) acc[row][ct] = b;
-    }
+                for (int ct = 0; ct < CT; ++ct) acc[row][ct] = Op<T>::mfma(f.w[dy][ct], f.x[row + dy], acc[row][ct]);
+    };
 
-    // fragment-read plan: pixel r+dx of halo row (4*wave + row + dy)
-    int rd_base[3];
-    int rd_swz[3];
+    f32x16 bias_v[CT];
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-        rd_base[dx] = (4 * wave) * (HALO_W * 4) + (r + dx) * 4;
-        rd_swz[dx] = ((r + dx) >> 2) & 3;
-    }
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bias_v[ct][i] = p.bias[32 * ct + (i & 3) + 8 * (i >> 2) + 4 * h];
 
-    stage(0, 0);
-    for (int c = 0; c < p.cin_chunks; ++c) {
-        // chunk c has landed (every wave waits for its own DMAs, then the barrier), and every wave is done
-        // reading the stage that is about to be refilled
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (c + 1 < p.cin_chunks) stage(c + 1, (c + 1) & 1);
+    const int nch = p.cin_chunks;
+    int st = 0;
+    issue((t_lo / tiles_x) * TILE_H, (t_lo % tiles_x) * TILE_W, 0, 0);
 
-        const uint4* a = lds + (c & 1) * BUF;
-        const uint4* wl = a + ACT_REGION + lane;
+    for (int t = t_lo; t < t_hi; ++t) {
+        const int y0 = (t / tiles_x) * TILE_H;
+        const int x0 = (t % tiles_x) * TILE_W;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int dy = t / 3;
-            const int dx = t - dy * 3;
+        for (int row = 0; row < 4; ++row)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                uint4 wf[CT];
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) wf[ct] = wl[((t * 2 + ks) * CT + ct) * 64];
-#pragma unroll
-                for (int row = 0; row < 4; ++row) {
-                    const uint4 xf = a[(row + dy) * (HALO_W * 4) + rd_base[dx] + ((2 * ks + h) ^ rd_swz[dx])];
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) acc[row][ct] = Op<T>::mfma(wf[ct], xf, acc[row][ct]);
-                }
-            }
+            for (int ct = 0; ct < CT; ++ct) acc[row][ct] = bias_v[ct];
+
+        for (int c = 0; c < nch; ++c) {
+            // this chunk has landed (each wave waits for its own DMAs, then the barrier) and every wave is done
+            // reading the other stage, which is refilled next
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (c + 1 < nch)
+                issue(y0, x0, c + 1, st ^ 1);
+            else if (t + 1 < t_hi)
+                issue(((t + 1) / tiles_x) * TILE_H, ((t + 1) % tiles_x) * TILE_W, 0, st ^ 1);
+
+            const uint4* a = lds + st * BUF;
+            const uint4* wl = a + ACT_REGION + lane;
+            Frags<CT> fa, fb;  // register double buffer: the next group's ds_reads fly under this group's MFMAs
+            load_group(fa, a, wl, 0);
+            load_group(fb, a, wl, 1);
+            mfma_group(fa);
+            load_group(fa, a, wl, 2);
+            mfma_group(fb);
+            load_group(fb, a, wl, 3);
+            mfma_group(fa);
+            load_group(fa, a, wl, 4);
+            mfma_group(fb);
+            load_group(fb, a, wl, 5);
+            mfma_group(fa);
+            mfma_group(fb);
+            st ^= 1;
         }
-    }
 
-    // ---- epilogue ---------------------------------------------------------------------------------------------
-    // The accumulators hold [cout][pixel] with the pixel on the lane; a store straight from registers would touch
-    // one cache line per lane.  Each wave transposes its own rows through LDS (row stride padded by 16 B: the
-    // ds_write_b128 of 8 consecutive pixels then hits 8 distinct 4-bank groups) and continues in a "pixel-major"
-    // layout where 8*CT consecutive lanes own one pixel's channels: residual loads, fp32 trunk stores and typed
-    // NHWC stores are then contiguous per pixel.
-    __syncthreads();  // every wave is done with the last chunk before LDS is reused
-    if constexpr (EPI == EPI_IMAGE) {
+        // ---- epilogue (the next tile's first chunk is already in flight) ----------------------------------------
         const int x = x0 + r;
 #pragma unroll
         for (int row = 0; row < 4; ++row) {
             const int y = y0 + 4 * wave + row;
-            if (h == 0 && y < p.img_H && x < p.img_W && y < p.H && x < p.W) {
-                const size_t pix = (size_t)y * p.img_W + x;
-                const float cr = acc[row][0][0], cg = acc[row][0][1], cb = acc[row][0][2];
-                if (p.out_rgb) {
-                    float* o = p.out_rgb + pix * 3;
-                    o[0] = cr;
-                    o[1] = cg;
-                    o[2] = cb;
-                }
-                if (p.out_u8) {
-                    uint8_t* o = p.out_u8 + pix * 3;
-                    o[0] = (uint8_t)rintf(fminf(fmaxf(cb, 0.f), 1.f) * 255.f);
-                    o[1] = (uint8_t)rintf(fminf(fmaxf(cg, 0.f), 1.f) * 255.f);
-                    o[2] = (uint8_t)rintf(fminf(fmaxf(cr, 0.f), 1.f) * 255.f);
-                }
-            }
-        }
-    } else {
-        constexpr int NC = 32 * CT;             // output channels
-        constexpr int ROWF = NC + 4;            // floats per pixel in the LDS scratch (16-byte pad)
-        constexpr int LPP = NC / 4;             // lanes per pixel in the pixel-major layout (8 or 16)
-        constexpr int PPI = 64 / LPP;           // pixels per wave-instruction (8 or 4)
-        float* scratch = reinterpret_cast<float*>(lds) + wave * (32 * ROWF);
-        const int c4 = (lane % LPP) * 4;        // this lane's 4 channels in the pixel-major layout
-        const int psub = lane / LPP;
-#pragma unroll
-        for (int row = 0; row < 4; ++row) {
-            const int y = y0 + 4 * wave + row;
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v = {acc[row][ct][4 * g], acc[row][ct][4 * g + 1], acc[row][ct][4 * g + 2],
-                               acc[row][ct][4 * g + 3]};
-                    *reinterpret_cast<f32x4*>(scratch + r * ROWF + 32 * ct + 8 * g + 4 * h) = v;
-                }
-            // same wave wrote what it reads: LDS operations of one wave complete in order
-#pragma unroll
-            for (int it = 0; it < 32 / PPI; ++it) {
-                const int px = it * PPI + psub;
-                const int x = x0 + px;
-                f32x4 o = *reinterpret_cast<const f32x4*>(scratch + px * ROWF + c4);
-                if (y < p.H && x < p.W) {
-                    const size_t pix = (size_t)y * p.W + x;
-                    if constexpr (EPI == EPI_RESIDUAL) {
-                        const f32x4 r1 = *reinterpret_cast<const f32x4*>(p.res1 + pix * NC + c4);
-                        o = o * p.s1 + r1;
-                        if (p.res2) {
-                            const f32x4 r2 = *reinterpret_cast<const f32x4*>(p.res2 + pix * NC + c4);
-                            o = o * p.s2 + r2;
-                        }
-                    } else {
-                        if (p.act) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.2f * o[j]);
-                        }
+            if (y >= p.H || x >= p.W) continue;
+            if constexpr (EPI == EPI_IMAGE) {
+                if (h == 0 && y < p.img_H && x < p.img_W) {
+                    const size_t pix = (size_t)y * p.img_W + x;
+                    const float cr = acc[row][0][0], cg = acc[row][0][1], cb = acc[row][0][2];
+                    if (p.out_rgb) {
+                        float* o = p.out_rgb + pix * 3;
+                        o[0] = cr;
+                        o[1] = cg;
+                        o[2] = cb;
                     }
-                    if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + pix * NC + c4) = o;
-                    if (p.out) {
-                        T* dst = reinterpret_cast<T*>(p.out) + pix * p.out_cstride + p.out_coff + c4;
-                        *reinterpret_cast<uint2*>(dst) = Op<T>::pack4(o[0], o[1], o[2], o[3]);
+                    if (p.out_u8) {
+                        uint8_t* o = p.out_u8 + pix * 3;
+                        o[0] = (uint8_t)rintf(fminf(fmaxf(cb, 0.f), 1.f) * 255.f);
+                        o[1] = (uint8_t)rintf(fminf(fmaxf(cg, 0.f), 1.f) * 255.f);
+                        o[2] = (uint8_t)rintf(fminf(fmaxf(cr, 0.f), 1.f) * 255.f);
+                    }
+                }
+            } else {
+                const size_t pix = (size_t)y * p.W + x;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int c0 = 32 * ct + 8 * g + 4 * h;
+                        float o[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = acc[row][ct][4 * g + j];
+                        if constexpr (EPI == EPI_RESIDUAL) {
+                            const f32x4 r1 = *reinterpret_cast<const f32x4*>(p.res1 + pix * (32 * CT) + c0);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[j] = o[j] * p.s1 + r1[j];
+                            if (p.res2) {
+                                const f32x4 r2 = *reinterpret_cast<const f32x4*>(p.res2 + pix * (32 * CT) + c0);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) o[j] = o[j] * p.s2 + r2[j];
+                            }
+                        } else {
+                            if (p.act) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.2f * o[j]);
+                            }
+                        }
+                        if (p.out_f32) {
+                            f32x4 of = {o[0], o[1], o[2], o[3]};
+                            *reinterpret_cast<f32x4*>(p.out_f32 + pix * (32 * CT) + c0) = of;
+                        }
+                        if (p.out) {
+                            T* dst = reinterpret_cast<T*>(p.out) + pix * p.out_cstride + p.out_coff + ct * p.out_pstride + 8 * g + 4 * h;
+                            *reinterpret_cast<uint2*>(dst) = Op<T>::pack4(o[0], o[1], o[2], o[3]);
+                        }
                     }
                 }
             }
@@ -296,10 +317,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(const ConvParams p
     }
 }
 
+static int num_cus() {
+    static int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        return v;
+    }();
+    return n;
+}
+
 template <typename T>
 static void launch_typed(int cout_tiles, ConvEpilogue epi, const ConvParams& p, hipStream_t stream) {
     const int tiles = ((p.W + TILE_W - 1) / TILE_W) * ((p.H + TILE_H - 1) / TILE_H);
-    dim3 grid(tiles), block(256);
+    // persistent workgroups: one per CU (LDS-limited), each walks a contiguous range of tiles
+    dim3 grid(tiles < num_cus() ? tiles : num_cus()), block(256);
     if (cout_tiles == 1 && epi == EPI_STORE)
         hipLaunchKernelGGL((conv3x3_mfma_kernel<T, 1, EPI_STORE>), grid, block, 0, stream, p);
     else if (cout_tiles == 2 && epi == EPI_STORE)
@@ -316,7 +349,11 @@ static void launch_typed(int cout_tiles, ConvEpilogue epi, const ConvParams& p, 
 void launch_conv3x3(DType dt, int cout_tiles, ConvEpilogue epi, const ConvParams& p, hipStream_t stream) {
     if (p.H <= 0 || p.W <= 0 || p.cin_chunks <= 0) throw Error(1, "conv3x3: empty problem");
     if (p.upsample2x && ((p.H | p.W) & 1)) throw Error(1, "conv3x3: upsample2x needs even output size");
-    if (p.in_cstride < 32 * p.cin_chunks || (p.in_cstride & 7)) throw Error(1, "conv3x3: bad input channel stride");
+    if (p.in_cstride < 32 || (p.in_cstride & 7) || p.in_pstride < 32 || (p.in_pstride & 7) ||
+        (p.in_pstride == 32 && p.in_cstride < 32 * p.cin_chunks))
+        throw Error(1, "conv3x3: bad input channel/plane stride");
+    if (p.out && cout_tiles == 2 && (p.out_pstride < 32 || (p.out_pstride & 3)))
+        throw Error(1, "conv3x3: bad output plane stride");
     if (p.out && ((p.out_cstride & 3) || (p.out_coff & 3))) throw Error(1, "conv3x3: output slice must be 8-byte aligned");
     if (dt == DT_BF16)
         launch_typed<__bf16>(cout_tiles, epi, p, stream);

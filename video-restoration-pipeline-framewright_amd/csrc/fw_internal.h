@@ -24,13 +24,16 @@ enum ConvEpilogue : int {
 
 struct ConvParams {
     const void* in;        // typed NHWC
-    int in_cstride;        // channels per pixel of the input buffer
+    int in_cstride;        // elements between consecutive pixels of the input buffer
+    long in_pstride;       // elements between consecutive 32-channel chunks (32 = interleaved NHWC; H*W*cstride =
+                           // chunk-planar, the layout the RRDB trunk uses: every chunk read is a contiguous stream)
     int cin_chunks;        // number of 32-channel chunks to contract over
     int H, W;              // OUTPUT height/width (input is H/2 x W/2 when upsample2x)
     const void* wpk;       // packed weight fragments (see pack_conv3x3_weights)
     const float* bias;     // [32*cout_tiles] (zero padded)
     void* out;             // typed NHWC output (may be null for EPI_IMAGE)
-    int out_cstride;       // channels per pixel of the output buffer
+    int out_cstride;       // elements between consecutive pixels of the output buffer
+    long out_pstride;      // elements between the two 32-channel halves of a 64-channel output (32 = interleaved)
     int out_coff;          // first channel written
     float* out_f32;        // optional fp32 NHWC copy, stride = 32*cout_tiles (EPI_STORE/EPI_RESIDUAL)
     const float* res1;     // fp32 NHWC stride 32*cout_tiles

@@ -200,20 +200,24 @@ void forward(fw_rrdbnet* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, f
 
     launch_u8_to_nhwc(n->dt, d_in, H, W, in32, 32, n->scale == 2 ? 2 : 1, st);
 
+    // chunk-planar activations: a 192-channel concat buffer is 6 planes of [Ht][Wt][32]
+    const long PL = (long)Ht * Wt * 32;
+    auto plane = [&](void* buf, int chunk, long pl) { return (void*)((char*)buf + (size_t)chunk * pl * 2); };
     ConvParams base{};
     base.H = Ht;
     base.W = Wt;
     base.s1 = 1.f;
     base.s2 = 1.f;
+    base.in_cstride = 32;
+    base.in_pstride = PL;
+    base.out_cstride = 32;
+    base.out_pstride = PL;
 
     // conv_first -> concat buffer 0 [0:64] + fp32 trunk F          (aesrgan_face.py:250)
     {
         ConvParams p = base;
         p.in = in32;
-        p.in_cstride = 32;
         p.out = cat[0];
-        p.out_cstride = 192;
-        p.out_coff = 0;
         p.out_f32 = F;
         run_conv(n, n->conv_first, EPI_STORE, p, st);
     }
@@ -227,20 +231,14 @@ void forward(fw_rrdbnet* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, f
             for (int c = 0; c < 4; ++c) {
                 ConvParams p = base;
                 p.in = cat[cur];
-                p.in_cstride = 192;
-                p.out = cat[cur];
-                p.out_cstride = 192;
-                p.out_coff = 64 + 32 * c;
+                p.out = plane(cat[cur], 2 + c, PL);
                 p.act = 1;
                 run_conv(n, L[c], EPI_STORE, p, st);
             }
             // conv5 + residual(s): x5*0.2 + x  (:188-189); after rdb3 additionally *0.2 + rrdb_in (:204)
             ConvParams p = base;
             p.in = cat[cur];
-            p.in_cstride = 192;
             p.out = cat[cur ^ 1];
-            p.out_cstride = 192;
-            p.out_coff = 0;
             p.s1 = 0.2f;
             p.res1 = (k == 0) ? Rin : (k == 1 ? tA : tB);
             if (k == 2) {
@@ -259,10 +257,7 @@ void forward(fw_rrdbnet* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, f
     {
         ConvParams p = base;
         p.in = cat[cur];
-        p.in_cstride = 192;
         p.out = cat[cur ^ 1];
-        p.out_cstride = 192;
-        p.out_coff = 0;
         p.res1 = F;
         p.s1 = 1.f;
         run_conv(n, n->conv_body, EPI_RESIDUAL, p, st);
@@ -274,10 +269,9 @@ void forward(fw_rrdbnet* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, f
         p.H = 2 * Ht;
         p.W = 2 * Wt;
         p.in = cat[cur];
-        p.in_cstride = 192;
         p.upsample2x = 1;
         p.out = U1;
-        p.out_cstride = 64;
+        p.out_pstride = 4 * PL;
         p.act = 1;
         run_conv(n, n->conv_up1, EPI_STORE, p, st);
     }
@@ -286,10 +280,10 @@ void forward(fw_rrdbnet* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, f
         p.H = 4 * Ht;
         p.W = 4 * Wt;
         p.in = U1;
-        p.in_cstride = 64;
+        p.in_pstride = 4 * PL;
         p.upsample2x = 1;
         p.out = U2;
-        p.out_cstride = 64;
+        p.out_pstride = 16 * PL;
         p.act = 1;
         run_conv(n, n->conv_up2, EPI_STORE, p, st);
     }
@@ -299,9 +293,9 @@ void forward(fw_rrdbnet* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, f
         p.H = 4 * Ht;
         p.W = 4 * Wt;
         p.in = U2;
-        p.in_cstride = 64;
+        p.in_pstride = 16 * PL;
         p.out = U3;
-        p.out_cstride = 64;
+        p.out_pstride = 16 * PL;
         p.act = 1;
         run_conv(n, n->conv_hr, EPI_STORE, p, st);
     }
@@ -310,7 +304,7 @@ void forward(fw_rrdbnet* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, f
         p.H = 4 * Ht;
         p.W = 4 * Wt;
         p.in = U3;
-        p.in_cstride = 64;
+        p.in_pstride = 16 * PL;
         p.out_u8 = d_out;
         p.out_rgb = d_rgb;
         p.img_H = n->scale * H;  // crops the mod-pad of the x2 model
@@ -516,10 +510,10 @@ size_t fw_pack_conv3x3(int dtype, const float* weight, int cout, int cin, int co
     return pack_conv3x3_weights((DType)dtype, weight, cout, cin, cout_tiles, cin_chunks, dst);
 }
 
-int fw_conv3x3_nhwc(int dtype, const void* x, int in_cstride, int cin_chunks, int H, int W, const void* packed_weight,
-                    const float* bias, int cout_tiles, int act_lrelu, int upsample2x, const float* res1, float s1,
-                    const float* res2, float s2, void* out, int out_cstride, int out_coff, float* out_f32,
-                    void* stream) {
+int fw_conv3x3_nhwc(int dtype, const void* x, int in_cstride, long in_plane_stride, int cin_chunks, int H, int W,
+                    const void* packed_weight, const float* bias, int cout_tiles, int act_lrelu, int upsample2x,
+                    const float* res1, float s1, const float* res2, float s2, void* out, int out_cstride,
+                    long out_plane_stride, int out_coff, float* out_f32, void* stream) {
     if (!x || !packed_weight || !bias) return fail(FW_ERR_INVALID, "fw_conv3x3_nhwc: NULL argument");
     if (dtype != FW_DTYPE_BF16 && dtype != FW_DTYPE_F16) return fail(FW_ERR_INVALID, "fw_conv3x3_nhwc: bad dtype");
     if (cout_tiles != 1 && cout_tiles != 2) return fail(FW_ERR_INVALID, "fw_conv3x3_nhwc: cout_tiles must be 1 or 2");
@@ -529,6 +523,8 @@ int fw_conv3x3_nhwc(int dtype, const void* x, int in_cstride, int cin_chunks, in
         ConvParams p{};
         p.in = x;
         p.in_cstride = in_cstride;
+        p.in_pstride = in_plane_stride > 0 ? in_plane_stride : 32;
+        p.out_pstride = out_plane_stride > 0 ? out_plane_stride : 32;
         p.cin_chunks = cin_chunks;
         p.H = H;
         p.W = W;
