@@ -20,6 +20,8 @@
 // chunk's weight fragments (18 KiB per 32 output channels) are staged global -> LDS by LDS-DMA
 // (global_load_lds_dwordx4) one chunk ahead, with an XOR swizzle that makes the ds_read_b128 fragment reads
 // bank-conflict free; both the halo tile and the weight fragments arrive by LDS-DMA, double buffered.
+#include <mutex>
+#include <cstdlib>
 #include "fw_internal.h"
 
 namespace fw {
@@ -62,9 +64,9 @@ constexpr int HALO_H = TILE_H + 2;                        // 18
 constexpr int HALO_W = TILE_W + 2;                        // 34
 constexpr int ROW_PIECES = HALO_W * 4;                    // 136 16-byte pieces per halo row
 constexpr int ACT_PIECES = HALO_H * ROW_PIECES;           // 2448 pieces per 32-channel chunk
-constexpr int ACT_INSTR = (ACT_PIECES + 63) / 64;         // 39 wave-instructions of 1 KiB
-constexpr int ACT_REGION = ACT_INSTR * 64;                // 2496 pieces (tail of the last instruction unused)
-constexpr int ACT_ITERS = (ACT_INSTR + 3) / 4;            // 10 per wave
+constexpr int ACT_INSTR = 40;                            // wave-instructions of 1 KiB per chunk (39 used + 1 pad)
+constexpr int ACT_REGION = ACT_INSTR * 64;                // 2560 pieces = 40 KiB per stage
+constexpr int ACT_ITERS = ACT_INSTR / 4;                  // 10 per wave, every wave issues all of them
 constexpr int W_FRAGS = 18;                               // 9 taps x 2 k-steps of 16, per cout tile
 
 // LDS image of one activation chunk: [halo row][halo px][4 slots of 16 B]; slot s (= 8 channels) of pixel p is
@@ -72,30 +74,33 @@ constexpr int W_FRAGS = 18;                               // 9 taps x 2 k-steps 
 // bank row positions (p & 3) * 64 + (s ^ ((p >> 2) & 3)) * 16: all 16 distinct -> conflict free.
 // The image is filled by LDS-DMA (global_load_lds_dwordx4): the LDS destination of a wave-instruction is
 // lane-linear, so the swizzle is applied on the per-lane SOURCE address (cdna_hip_programming.md rule 21).
+// Lanes whose halo position is outside the image read a 16-byte zero page instead, so every wave issues the same
+// number of DMA instructions per stage (the counted s_waitcnt vmcnt below relies on it) and zero padding costs
+// nothing.
 
 template <int CT>
 struct Smem {
-    static constexpr int BUF = ACT_REGION + W_FRAGS * CT * 64;  // pieces per pipeline stage
-    static constexpr int TOTAL = 2 * BUF;                       // double buffered
+    static constexpr int NA = CT == 1 ? 3 : 2;                  // activation stages in flight
+    static constexpr int W_ITERS = (W_FRAGS * CT + 3) / 4;      // weight DMAs per wave per stage (5 or 9)
+    static constexpr int W_REGION = W_ITERS * 4 * 64;           // pieces per weight stage (incl. pad fragments)
+    static constexpr int W_BASE = NA * ACT_REGION;
+    static constexpr int TOTAL = NA * ACT_REGION + 2 * W_REGION;  // CT=1: 160 KiB exactly; CT=2: 152 KiB
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-// One global_load_lds_dwordx4: every active lane copies 16 bytes from (base + voff) to LDS[lds_dst + 16 * lane];
-// base and lds_dst are wave-uniform.  Inline asm so that hipcc does not count these loads: with the builtin it
-// drains them (s_waitcnt vmcnt(0)) before the first ds_read of the chunk being computed, which serialises the
-// pipeline (cdna_hip_programming.md §5 "Three .s-level traps" (b)).  The matching wait is the explicit vmcnt(0)
-// at the top of the chunk loop.  M0 is written and restored inside the statement (§5.7).
-__device__ __forceinline__ void glds16(const void* base, unsigned voff, unsigned lds_dst) {
-    unsigned keep;
+// One global_load_lds_dwordx4: every lane copies 16 bytes from its own global address to LDS[lds_dst + 16 * lane];
+// lds_dst is wave-uniform.  Inline asm so that hipcc does not count these loads: with the builtin it drains them
+// (s_waitcnt vmcnt(0)) before the first ds_read of the chunk being computed, which serialises the pipeline
+// (cdna_hip_programming.md §5 "Three .s-level traps" (b)).  The matching waits are the explicit counted vmcnt at
+// the top of the chunk loop.  M0 is written inside the statement; nothing else in this kernel uses M0.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
     asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
+        "s_mov_b32 m0, %1\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(base), "s"(lds_dst)
+        "global_load_lds_dwordx4 %0, off"
+        :
+        : "v"(gsrc), "s"(lds_dst)
         : "memory");
 }
 
@@ -107,10 +112,13 @@ struct Frags {
     uint4 w[3][CT];
 };
 
+#define FW_SB() __builtin_amdgcn_sched_barrier(0)
+
 template <typename T, int CT, int EPI>
 __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(const ConvParams p) {
-    __shared__ __attribute__((aligned(16))) uint4 lds[Smem<CT>::TOTAL];
-    constexpr int BUF = Smem<CT>::BUF;
+    using SM = Smem<CT>;
+    __shared__ __attribute__((aligned(16))) uint4 lds[SM::TOTAL];
+    constexpr int NA = SM::NA;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -130,13 +138,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(const ConvParams p
     const int t_lo = (int)((long)lb * ntiles / NB);
     const int t_hi = (int)((long)(lb + 1) * ntiles / NB);
     if (t_lo >= t_hi) return;
+    const int nch = p.cin_chunks;
+    const int nitems = (t_hi - t_lo) * nch;  // (tile, chunk) pairs, walked as one pipelined sequence
 
-    // ---- tile-invariant per-lane DMA plan -----------------------------------------------------------------------
+    // ---- per-lane DMA plan ------------------------------------------------------------------------------------
     const int ups = p.upsample2x;
     const int Ws = ups ? (p.W >> 1) : p.W;
-    const long org = ((long)Ws + 1) * p.in_cstride;  // elements between the DMA base and the tile origin
-    unsigned rel[ACT_ITERS];                          // byte offset of this lane's piece from the DMA base
-    int rp[ACT_ITERS];                                // (halo row << 8) | halo px, or -1 for the unused tail
+    int rel[ACT_ITERS];  // element offset of this lane's piece from the tile origin (may be negative)
+    int rp[ACT_ITERS];   // (halo row << 8) | halo px, or -1 for the pad pieces
 #pragma unroll
     for (int i = 0; i < ACT_ITERS; ++i) {
         const int idx = (wave + 4 * i) * 64 + lane;
@@ -146,38 +155,51 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(const ConvParams p
         const int s = (rm & 3) ^ ((px >> 2) & 3);  // which 8-channel slot lands at this LDS position
         const int srow = ups ? ((row - 1) >> 1) : (row - 1);
         const int spx = ups ? ((px - 1) >> 1) : (px - 1);
-        rel[i] = (unsigned)(((long)srow * Ws + spx) * p.in_cstride + s * 8 + org) * 2u;
+        rel[i] = (srow * Ws + spx) * p.in_cstride + s * 8;
         rp[i] = (idx < ACT_PIECES) ? ((row << 8) | px) : -1;
     }
     const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)lds;
-    const char* in_b = reinterpret_cast<const char*>(p.in);
-    const char* w_b = reinterpret_cast<const char*>(p.wpk);
+    const T* in = reinterpret_cast<const T*>(p.in);
+    const char* w_b = reinterpret_cast<const char*>(p.wpk) + lane * 16;
+    const unsigned chunk_bytes = (unsigned)(p.in_pstride * 2);
 
-    // DMA of (tile origin ty0/tx0, chunk c) into pipeline stage `st`; positions outside the image are zeroed.
-    auto issue = [&](int ty0, int tx0, int c, int st) {
+    // The activation DMA stream runs NA-1 items ahead of the compute and walks (tile, chunk) in order: a_t/a_c
+    // is the item it issues next, src[]/inc[] the per-lane source of that item (zero page outside the image).
+    const char* src[ACT_ITERS];
+    unsigned inc[ACT_ITERS];
+    int a_n = 0, a_t = t_lo, a_c = 0;
+    auto plan_tile = [&]() {
+        const int ty0 = (a_t / tiles_x) * TILE_H, tx0 = (a_t % tiles_x) * TILE_W;
         const int sy0 = ups ? (ty0 >> 1) : ty0;
         const int sx0 = ups ? (tx0 >> 1) : tx0;
-        const char* base = in_b + (((long)sy0 * Ws + sx0) * p.in_cstride - org + c * p.in_pstride) * 2;
-        const unsigned dst = lds_base + (unsigned)(st * BUF) * 16u;
+        const T* base = in + ((long)sy0 * Ws + sx0) * p.in_cstride;
 #pragma unroll
         for (int i = 0; i < ACT_ITERS; ++i) {
-            const int j = wave + 4 * i;
-            if (j < ACT_INSTR) {
-                const int gy = ty0 - 1 + (rp[i] >> 8);
-                const int gx = tx0 - 1 + (rp[i] & 255);
-                const bool ok = rp[i] >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-                if (ok)
-                    glds16(base, rel[i], dst + (unsigned)j * 1024u);
-                else if (rp[i] >= 0)
-                    lds[st * BUF + j * 64 + lane] = make_uint4(0, 0, 0, 0);
+            const int gy = ty0 - 1 + (rp[i] >> 8);
+            const int gx = tx0 - 1 + (rp[i] & 255);
+            const bool ok = rp[i] >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            src[i] = ok ? reinterpret_cast<const char*>(base + rel[i]) : reinterpret_cast<const char*>(p.zeros);
+            inc[i] = ok ? chunk_bytes : 0u;
+        }
+    };
+    // DMA number i (0..ACT_ITERS-1) of the next activation item
+    auto issue_act_one = [&](int i) {
+        if (i == 0 && a_c == 0) plan_tile();
+        glds16(src[i], lds_base + (unsigned)((a_n % NA) * ACT_REGION + (wave + 4 * i) * 64) * 16u);
+        src[i] += inc[i];
+        if (i == ACT_ITERS - 1) {
+            ++a_n;
+            if (++a_c == nch) {
+                a_c = 0;
+                ++a_t;
             }
         }
-        const char* wc = w_b + (size_t)c * (W_FRAGS * CT * 1024);
-#pragma unroll
-        for (int i = 0; i < (W_FRAGS * CT + 3) / 4; ++i) {
-            const int f = wave + 4 * i;
-            if (f < W_FRAGS * CT) glds16(wc + f * 1024, (unsigned)lane * 16u, dst + (unsigned)(ACT_REGION + f * 64) * 16u);
-        }
+    };
+    // DMA number i (0..W_ITERS-1) of the weights of chunk c into weight stage ws (pad fragments re-load fragment 0)
+    auto issue_w_one = [&](int i, int c, int ws) {
+        const int f = wave + 4 * i;
+        glds16(w_b + (size_t)c * (W_FRAGS * CT * 1024) + (f < W_FRAGS * CT ? f : 0) * 1024,
+               lds_base + (unsigned)(SM::W_BASE + ws * SM::W_REGION + f * 64) * 16u);
     };
 
     // ---- fragment-read plan ------------------------------------------------------------------------------------
@@ -199,25 +221,30 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(const ConvParams p
     };
 
     f32x16 acc[4][CT];
-    auto mfma_group = [&](const Frags<CT>& f) {
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int row = 0; row < 4; ++row)
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc[row][ct] = Op<T>::mfma(f.w[dy][ct], f.x[row + dy], acc[row][ct]);
-    };
-
     f32x16 bias_v[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int i = 0; i < 16; ++i) bias_v[ct][i] = p.bias[32 * ct + (i & 3) + 8 * (i >> 2) + 4 * h];
 
-    const int nch = p.cin_chunks;
-    int st = 0;
-    issue((t_lo / tiles_x) * TILE_H, (t_lo % tiles_x) * TILE_W, 0, 0);
+    // ---- pipeline prologue ------------------------------------------------------------------------------------
+    // Issue order per boundary is [weights(n+1), activations(n+NA-1)]; vmcnt retires in order, so at boundary n
+    // "all but the youngest ACT_ITERS DMAs" == everything up to and including weights(n) and activations(n).
+#pragma unroll
+    for (int i = 0; i < SM::W_ITERS; ++i) issue_w_one(i, 0, 0);
+#pragma unroll
+    for (int i = 0; i < ACT_ITERS; ++i) issue_act_one(i);
+    if (NA == 3 && nitems > 1) {
+#pragma unroll
+        for (int i = 0; i < ACT_ITERS; ++i) issue_act_one(i);
+    }
 
+    // timing ablations: build with -DFW_CONV_DEBUG=<bits> (1 = no MFMA, 2 = no LDS-DMA, 4 = no epilogue)
+#ifndef FW_CONV_DEBUG
+#define FW_CONV_DEBUG 0
+#endif
+    constexpr int dbg = FW_CONV_DEBUG;
+    int n = 0;
     for (int t = t_lo; t < t_hi; ++t) {
         const int y0 = (t / tiles_x) * TILE_H;
         const int x0 = (t % tiles_x) * TILE_W;
@@ -226,42 +253,83 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(const ConvParams p
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) acc[row][ct] = bias_v[ct];
 
-        for (int c = 0; c < nch; ++c) {
-            // this chunk has landed (each wave waits for its own DMAs, then the barrier) and every wave is done
-            // reading the other stage, which is refilled next
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int c = 0; c < nch; ++c, ++n) {
+            // item n has landed (each wave waits for its own DMAs, then the barrier) and every wave is done reading
+            // the stages that are refilled during this item
+            if (NA == 3 && n + 1 < nitems)
+                asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // ACT_ITERS: activations(n+1) may stay in flight
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (c + 1 < nch)
-                issue(y0, x0, c + 1, st ^ 1);
-            else if (t + 1 < t_hi)
-                issue(((t + 1) / tiles_x) * TILE_H, ((t + 1) % tiles_x) * TILE_W, 0, st ^ 1);
+            const bool do_w = n + 1 < nitems && !(dbg & 2);
+            const bool do_a = n + NA - 1 < nitems && !(dbg & 2);
+            const int c1 = (c + 1 == nch) ? 0 : c + 1;
+            // The W_ITERS + ACT_ITERS DMAs of this boundary are issued one at a time in the shadow of the MFMAs
+            // (an MFMA occupies the issue port for 8 of its 32 cycles): slot d of group gi, compile-time after
+            // unrolling.
+            auto dma_slot = [&](int d) {
+                if (d < SM::W_ITERS) {
+                    if (do_w) issue_w_one(d, c1, (n + 1) & 1);
+                } else if (d - SM::W_ITERS < ACT_ITERS) {
+                    if (do_a) issue_act_one(d - SM::W_ITERS);
+                }
+            };
+            auto mfma_group = [&](const Frags<CT>& f, int gi) {
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int row = 0; row < 4; ++row) {
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+                            if (!(dbg & 1)) acc[row][ct] = Op<T>::mfma(f.w[dy][ct], f.x[row + dy], acc[row][ct]);
+                        if (row & 1) {
+                            FW_SB();
+                            dma_slot(gi * 6 + dy * 2 + (row >> 1));
+                            FW_SB();
+                        }
+                    }
+            };
 
-            const uint4* a = lds + st * BUF;
-            const uint4* wl = a + ACT_REGION + lane;
-            Frags<CT> fa, fb;  // register double buffer: the next group's ds_reads fly under this group's MFMAs
+            const uint4* a = lds + (n % NA) * ACT_REGION;
+            const uint4* wl = lds + SM::W_BASE + (n & 1) * SM::W_REGION + lane;
+            // register double buffer: the next group's ds_reads fly under this group's MFMAs.  sched_barrier(0)
+            // pins that order: left alone, hipcc sinks every ds_read to just before its first use, and with one wave
+            // per SIMD each group then eats a full LDS round trip.
+            Frags<CT> fa, fb;
             load_group(fa, a, wl, 0);
+            FW_SB();
             load_group(fb, a, wl, 1);
-            mfma_group(fa);
+            FW_SB();
+            mfma_group(fa, 0);
+            FW_SB();
             load_group(fa, a, wl, 2);
-            mfma_group(fb);
+            FW_SB();
+            mfma_group(fb, 1);
+            FW_SB();
             load_group(fb, a, wl, 3);
-            mfma_group(fa);
+            FW_SB();
+            mfma_group(fa, 2);
+            FW_SB();
             load_group(fa, a, wl, 4);
-            mfma_group(fb);
+            FW_SB();
+            mfma_group(fb, 3);
+            FW_SB();
             load_group(fb, a, wl, 5);
-            mfma_group(fa);
-            mfma_group(fb);
-            st ^= 1;
+            FW_SB();
+            mfma_group(fa, 4);
+            FW_SB();
+            mfma_group(fb, 5);
+            FW_SB();
         }
 
-        // ---- epilogue (the next tile's first chunk is already in flight) ----------------------------------------
-        const int x = x0 + r;
+        // ---- epilogue (the DMA stream is already fetching the next tile) -----------------------------------------
+        if (dbg & 4) continue;
+        if constexpr (EPI == EPI_IMAGE) {
+            const int x = x0 + r;
 #pragma unroll
-        for (int row = 0; row < 4; ++row) {
-            const int y = y0 + 4 * wave + row;
-            if (y >= p.H || x >= p.W) continue;
-            if constexpr (EPI == EPI_IMAGE) {
-                if (h == 0 && y < p.img_H && x < p.img_W) {
+            for (int row = 0; row < 4; ++row) {
+                const int y = y0 + 4 * wave + row;
+                if (h == 0 && y < p.img_H && x < p.img_W && y < p.H && x < p.W) {
                     const size_t pix = (size_t)y * p.img_W + x;
                     const float cr = acc[row][0][0], cg = acc[row][0][1], cb = acc[row][0][2];
                     if (p.out_rgb) {
@@ -277,24 +345,32 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(const ConvParams p
                         o[2] = (uint8_t)rintf(fminf(fmaxf(cr, 0.f), 1.f) * 255.f);
                     }
                 }
-            } else {
+            }
+        } else {
+            constexpr int NC = 32 * CT;
+            // (1) fp32 side: residuals in, trunk out.  Native layout = the accumulator fragment order
+            //     [tile][wave][row][ct][g][lane][4], one contiguous KiB per wave-instruction, no transposition;
+            //     NHWC (op-level API) is the slow general form.
+#pragma unroll
+            for (int row = 0; row < 4; ++row) {
+                const int y = y0 + 4 * wave + row;
+                const int x = x0 + r;
+                const bool inside = y < p.H && x < p.W;
                 const size_t pix = (size_t)y * p.W + x;
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
+                for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const int c0 = 32 * ct + 8 * g + 4 * h;
-                        float o[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = acc[row][ct][4 * g + j];
+                        const size_t nat = ((((((size_t)t * 4 + wave) * 4 + row) * CT + ct) * 4 + g) * 64 + lane) * 4;
+                        const size_t lin = pix * NC + 32 * ct + 8 * g + 4 * h;
+                        const size_t fo = p.f32_native ? nat : lin;
+                        const bool fok = p.f32_native || inside;
+                        f32x4 o = {acc[row][ct][4 * g], acc[row][ct][4 * g + 1], acc[row][ct][4 * g + 2],
+                                   acc[row][ct][4 * g + 3]};
                         if constexpr (EPI == EPI_RESIDUAL) {
-                            const f32x4 r1 = *reinterpret_cast<const f32x4*>(p.res1 + pix * (32 * CT) + c0);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) o[j] = o[j] * p.s1 + r1[j];
-                            if (p.res2) {
-                                const f32x4 r2 = *reinterpret_cast<const f32x4*>(p.res2 + pix * (32 * CT) + c0);
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) o[j] = o[j] * p.s2 + r2[j];
+                            if (fok) {
+                                o = o * p.s1 + *reinterpret_cast<const f32x4*>(p.res1 + fo);
+                                if (p.res2) o = o * p.s2 + *reinterpret_cast<const f32x4*>(p.res2 + fo);
                             }
                         } else {
                             if (p.act) {
@@ -302,19 +378,80 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(const ConvParams p
                                 for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.2f * o[j]);
                             }
                         }
-                        if (p.out_f32) {
-                            f32x4 of = {o[0], o[1], o[2], o[3]};
-                            *reinterpret_cast<f32x4*>(p.out_f32 + pix * (32 * CT) + c0) = of;
+                        if (p.out_f32 && fok) *reinterpret_cast<f32x4*>(p.out_f32 + fo) = o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[row][ct][4 * g + j] = o[j];
+                    }
+            }
+            // (2) typed NHWC output: transpose each row through LDS so that one wave-instruction stores whole
+            //     pixels (16 B per lane, contiguous).  Scratch = halo rows 4w+2, 4w+3 of the activation stage just
+            //     consumed: no other wave reads them, and the stage is refilled only after the next barrier.
+            if (p.out) {
+                constexpr int PSTR = CT == 1 ? 80 : 136;   // bytes per pixel in scratch (padded: conflict-free writes)
+                char* scr = reinterpret_cast<char*>(lds + ((n - 1) % NA) * ACT_REGION + (4 * wave + 2) * ROW_PIECES);
+                T* outp = reinterpret_cast<T*>(p.out);
+#pragma unroll
+                for (int row = 0; row < 4; ++row) {
+                    const int y = y0 + 4 * wave + row;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<uint2*>(scr + r * PSTR + ct * 64 + (8 * g + 4 * h) * 2) =
+                                Op<T>::pack4(acc[row][ct][4 * g], acc[row][ct][4 * g + 1], acc[row][ct][4 * g + 2],
+                                             acc[row][ct][4 * g + 3]);
+                    constexpr int LPP = 4 * CT;  // lanes per pixel (16 B each)
+                    constexpr int PPI = 64 / LPP;
+#pragma unroll
+                    for (int it = 0; it < 32 / PPI; ++it) {
+                        const int px = it * PPI + lane / LPP;
+                        const int q = lane % LPP;
+                        uint4 v;
+                        if constexpr (CT == 1) {
+                            v = *reinterpret_cast<const uint4*>(scr + px * PSTR + q * 16);
+                        } else {
+                            const uint2 lo = *reinterpret_cast<const uint2*>(scr + px * PSTR + q * 16);
+                            const uint2 hi = *reinterpret_cast<const uint2*>(scr + px * PSTR + q * 16 + 8);
+                            v = make_uint4(lo.x, lo.y, hi.x, hi.y);
                         }
-                        if (p.out) {
-                            T* dst = reinterpret_cast<T*>(p.out) + pix * p.out_cstride + p.out_coff + ct * p.out_pstride + 8 * g + 4 * h;
-                            *reinterpret_cast<uint2*>(dst) = Op<T>::pack4(o[0], o[1], o[2], o[3]);
+                        const int x = x0 + px;
+                        if (y < p.H && x < p.W) {
+                            T* dst = outp + ((size_t)y * p.W + x) * p.out_cstride + p.out_coff + (q >> 2) * p.out_pstride +
+                                     (q & 3) * 8;
+                            *reinterpret_cast<uint4*>(dst) = v;
                         }
                     }
                 }
             }
         }
     }
+}
+
+#undef FW_SB
+
+static_assert(ACT_ITERS == 10, "the counted s_waitcnt vmcnt(10) in the kernel assumes 10 activation DMAs per wave");
+
+// 256 bytes of zeros per device: the DMA source of halo positions outside the image.
+static const void* zero_page() {
+    static std::mutex mu;
+    static void* pages[64] = {};
+    int dev = 0;
+    FW_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) throw Error(1, "conv3x3: device ordinal out of range");
+    std::lock_guard<std::mutex> lk(mu);
+    if (!pages[dev]) {
+        void* z = nullptr;
+        FW_HIP_CHECK(hipMalloc(&z, 256));
+        FW_HIP_CHECK(hipMemset(z, 0, 256));
+        FW_HIP_CHECK(hipDeviceSynchronize());
+        pages[dev] = z;
+    }
+    return pages[dev];
+}
+
+size_t f32_native_elems(int H, int W, int cout_tiles) {
+    const size_t tiles = (size_t)((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
+    return tiles * (TILE_H * TILE_W) * 32 * cout_tiles;
 }
 
 static int num_cus() {
@@ -346,15 +483,19 @@ static void launch_typed(int cout_tiles, ConvEpilogue epi, const ConvParams& p, 
     FW_HIP_CHECK(hipGetLastError());
 }
 
-void launch_conv3x3(DType dt, int cout_tiles, ConvEpilogue epi, const ConvParams& p, hipStream_t stream) {
+void launch_conv3x3(DType dt, int cout_tiles, ConvEpilogue epi, const ConvParams& p_in, hipStream_t stream) {
+    ConvParams p = p_in;
+    p.zeros = zero_page();
+
+
     if (p.H <= 0 || p.W <= 0 || p.cin_chunks <= 0) throw Error(1, "conv3x3: empty problem");
     if (p.upsample2x && ((p.H | p.W) & 1)) throw Error(1, "conv3x3: upsample2x needs even output size");
     if (p.in_cstride < 32 || (p.in_cstride & 7) || p.in_pstride < 32 || (p.in_pstride & 7) ||
         (p.in_pstride == 32 && p.in_cstride < 32 * p.cin_chunks))
         throw Error(1, "conv3x3: bad input channel/plane stride");
-    if (p.out && cout_tiles == 2 && (p.out_pstride < 32 || (p.out_pstride & 3)))
+    if (p.out && cout_tiles == 2 && (p.out_pstride < 32 || (p.out_pstride & 7)))
         throw Error(1, "conv3x3: bad output plane stride");
-    if (p.out && ((p.out_cstride & 3) || (p.out_coff & 3))) throw Error(1, "conv3x3: output slice must be 8-byte aligned");
+    if (p.out && ((p.out_cstride & 7) || (p.out_coff & 7))) throw Error(1, "conv3x3: output slice must be 16-byte aligned");
     if (dt == DT_BF16)
         launch_typed<__bf16>(cout_tiles, epi, p, stream);
     else

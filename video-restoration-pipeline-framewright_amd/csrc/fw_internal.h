@@ -44,7 +44,13 @@ struct ConvParams {
     int img_H, img_W;      // EPI_IMAGE: size of the stored image (crop of the H x W conv output; mod-pad removal)
     int act;               // 1 = LeakyReLU(0.2) (EPI_STORE only)
     int upsample2x;        // 1 = input is nearest-neighbour x2 upsampled on the fly
+    int f32_native;        // 1: res1/res2/out_f32 use the accumulator-native layout (see f32_native_elems)
+    const void* zeros;     // >= 16 bytes of zeros in device memory (set by launch_conv3x3)
 };
+
+// Number of floats of an accumulator-native fp32 side buffer for an H x W problem with 32*cout_tiles channels:
+// [tile][wave][row][ct][g][lane][4] over the padded 16x32 tile grid.
+size_t f32_native_elems(int H, int W, int cout_tiles);
 
 // Launches the kernel; cout_tiles in {1,2} (32 or 64 output channels).
 void launch_conv3x3(DType dt, int cout_tiles, ConvEpilogue epi, const ConvParams& p, hipStream_t stream);

@@ -119,10 +119,11 @@ Plan make_plan(const fw_rrdbnet* n, int H, int W) {
     p.in32 = take(px * 32 * 2);
     p.cat0 = take(px * 192 * 2);
     p.cat1 = take(px * 192 * 2);
-    p.F = take(px * 64 * 4);
-    p.R = take(px * 64 * 4);
-    p.tA = take(px * 64 * 4);
-    p.tB = take(px * 64 * 4);
+    const size_t trunk = f32_native_elems(Ht, Wt, 2) * 4;  // fp32 trunk buffers, accumulator-native layout
+    p.F = take(trunk);
+    p.R = take(trunk);
+    p.tA = take(trunk);
+    p.tB = take(trunk);
     p.U1 = take(px * 4 * 64 * 2);
     p.U2 = take(px * 16 * 64 * 2);
     p.U3 = take(px * 16 * 64 * 2);
@@ -212,6 +213,7 @@ void forward(fw_rrdbnet* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, f
     base.in_pstride = PL;
     base.out_cstride = 32;
     base.out_pstride = PL;
+    base.f32_native = 1;
 
     // conv_first -> concat buffer 0 [0:64] + fp32 trunk F          (aesrgan_face.py:250)
     {
