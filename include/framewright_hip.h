@@ -44,6 +44,7 @@ extern "C" {
 #define FW_DTYPE_F16 1
 
 typedef struct fw_rrdbnet fw_rrdbnet;
+typedef struct fw_nafnet fw_nafnet;
 
 /* -------------------------------------------------------------------------------------------------
  * Library
@@ -129,6 +130,56 @@ int fw_conv3x3_nhwc(int dtype, const void* x, int in_cstride, long in_plane_stri
                     int width, const void* packed_weight, const float* bias, int cout_tiles, int act_lrelu,
                     int upsample2x, const float* res1, float s1, const float* res2, float s2, void* out,
                     int out_cstride, long out_plane_stride, int out_coff, float* out_f32, void* stream);
+
+/* -------------------------------------------------------------------------------------------------
+ * TAP temporal denoise: NAFNet
+ * replaces  basicsr NAFNet construction + load in TAPDenoiser._load_nafnet (processors/tap_denoise.py:335-364),
+ *           _preprocess_frame / self._model(tensor) / _postprocess_frame (:373-415, :431-434, :455-459).
+ * ------------------------------------------------------------------------------------------------- */
+
+/* NAFNet(img_channel=3, width, middle_blk_num, enc_blk_nums[num_levels], dec_blk_nums[num_levels]); the reference
+ * passes width=64, middle=12, enc=[2,2,4,8], dec=[2,2,2,2] (tap_denoise.py:340-346).  width in {32, 64}. */
+int fw_nafnet_create(int device_id, int width, int middle_blk_num, const int* enc_blk_nums, const int* dec_blk_nums,
+                     int num_levels, int dtype, fw_nafnet** out);
+
+/* Upload one state-dict tensor by its key (host fp32, torch layout, `numel` elements): intro.weight/bias,
+ * ending.weight/bias, downs.{l}.weight/bias, ups.{i}.0.weight, {encoders.{l}.{j} | middle_blks.{j} |
+ * decoders.{i}.{j}}.{norm1,norm2}.{weight,bias} / conv{1..5}.{weight,bias} / sca.1.{weight,bias} / beta / gamma. */
+int fw_nafnet_set_tensor(fw_nafnet* net, const char* key, const float* data, size_t numel);
+int fw_nafnet_finalize(fw_nafnet* net);
+
+/* One frame (or tile): uint8 BGR H x W x 3 -> uint8 BGR H x W x 3.  BGR->RGB, /255, zero pad to a multiple of
+ * 2^num_levels, NAFNet forward (+ input residual), crop, np.clip(x*255, 0, 255).astype(uint8) — truncation, as
+ * tap_denoise.py:412 — RGB->BGR.  out_rgb_f32 (optional, device, H x W x 3 RGB) receives the un-quantised output. */
+int fw_nafnet_denoise_u8(fw_nafnet* net, const uint8_t* in_bgr, int in_loc, int height, int width, uint8_t* out_bgr,
+                         int out_loc, float* out_rgb_f32, void* stream);
+double fw_nafnet_flops(const fw_nafnet* net, int height, int width);
+int fw_nafnet_destroy(fw_nafnet* net);
+
+/* -------------------------------------------------------------------------------------------------
+ * TAP driver arithmetic on uint8 frames (all pointers device memory; bit-exact restatements)
+ * ------------------------------------------------------------------------------------------------- */
+
+/* dst[th][tw][3] = src[y0:y0+th, x0:x0+tw]               (frame[y1:y2, x1:x2], tap_denoise.py:452) */
+int fw_u8_crop(const uint8_t* src, int height, int width, int y0, int x0, int th, int tw, uint8_t* dst, void* stream);
+
+/* output[y0:.., x0:..] += tile * tile_weight ; weight[...] += tile_weight, with the linear ramps of
+ * tap_denoise.py:461-486 on the tile edges that are interior to the frame (np.linspace(0, 1, overlap)). */
+int fw_tile_blend_accumulate(float* acc, float* wsum, int height, int width, const uint8_t* tile, int y0, int x0, int th,
+                             int tw, int overlap, void* stream);
+
+/* out = (output / max(weight, 1e-8)).astype(uint8)        (tap_denoise.py:484-486) */
+int fw_tile_blend_finish(const float* acc, const float* wsum, int height, int width, uint8_t* out, void* stream);
+
+/* result = sum_k float32(frame_k) * float32(w_k) accumulated in float32, .astype(uint8)   (tap_denoise.py:526-534).
+ * `frames` is a HOST array of `count` (<= 16) DEVICE pointers; weights are the normalised host weights. */
+int fw_temporal_average_u8(const uint8_t* const* frames, const float* weights, int count, size_t nbytes, uint8_t* out,
+                           void* stream);
+
+/* out = (original * (1 - s) + denoised * s).astype(uint8)  (tap_denoise.py:614-618); s is a double like the
+ * reference's Python float: (1 - s) is formed in double, then both factors are rounded once to float32. */
+int fw_strength_blend_u8(const uint8_t* original, const uint8_t* denoised, double strength, size_t nbytes, uint8_t* out,
+                         void* stream);
 
 #ifdef __cplusplus
 }

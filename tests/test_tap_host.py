@@ -1,0 +1,62 @@
+"""TAP driver host logic (no GPU): tile grid, temporal weights, config validation — mirrors the reference's
+tests/test_processors/test_tap_denoise.py (defaults / validation / MODEL_FILES) and pins the integer bookkeeping of
+reference tap_denoise.py:435-450,508-528 on values worked out by hand from those formulas."""
+import numpy as np
+import pytest
+import torch
+
+from framewright_amd import tap_denoise as T
+from oracle import tap_ref
+
+
+def test_config_defaults_and_validation():
+    c = T.TAPDenoiseConfig()
+    assert (c.temporal_window, c.strength, c.preserve_grain, c.half_precision, c.tile_size, c.tile_overlap, c.gpu_id,
+            c.batch_size) == (5, 1.0, False, True, 512, 32, 0, 1)
+    assert T.TAPDenoiseConfig(model="nafnet").model is T.TAPModel.NAFNET
+    for bad in (dict(temporal_window=0), dict(strength=1.5), dict(strength=-0.1), dict(tile_size=-1), dict(tile_overlap=-1)):
+        with pytest.raises(ValueError):
+            T.TAPDenoiseConfig(**bad)
+
+
+def test_model_files_match_reference():
+    assert T.TAPDenoiser.MODEL_FILES[T.TAPModel.NAFNET] == "NAFNet-SIDD-width64.pth"
+    assert T.TAPDenoiser.MODEL_FILES[T.TAPModel.RESTORMER] == "restormer_deraining.pth"
+    assert T.TAPDenoiser.DEFAULT_MODEL_DIR.parts[-3:] == (".framewright", "models", "tap")
+    assert [m.value for m in T.TAPModel] == ["restormer", "nafnet", "tap"]
+
+
+def test_tile_grid_1080p_is_3_by_4():
+    g = T.tile_grid(1080, 1920, 512, 32)           # stride 480: h: (1048//480)+1 = 3, w: (1888//480)+1 = 4
+    assert len(g) == 12
+    assert sorted({y for y, _ in g}) == [0, 480, 568]     # last row clamps to h - tile
+    assert sorted({x for _, x in g}) == [0, 480, 960, 1408]
+    assert g == tap_ref.tile_grid(1080, 1920, 512, 32)
+    assert T.tile_grid(512, 512, 512, 32) == [(0, 0)]
+    assert T.tile_grid(992, 512, 512, 32) == [(0, 0), (480, 0)]   # (960 % 480 == 0) -> exactly 2 rows
+    with pytest.raises(ValueError):
+        T.tile_grid(100, 100, 32, 32)
+
+
+def test_temporal_weights():
+    s, e, w = T.temporal_window(10, 5, 5)
+    assert (s, e) == (3, 8)
+    raw = np.array([0.5, 1 / 1.5, 1.0, 1 / 1.5, 0.5])
+    assert np.allclose(w, raw / raw.sum())
+    s, e, w = T.temporal_window(10, 0, 5)          # clip start clamps the window (tap_denoise.py:510)
+    assert (s, e) == (0, 3) and np.allclose(w, np.array([1.0, 1 / 1.5, 0.5]) / (1 + 1 / 1.5 + 0.5))
+    s, e, w = T.temporal_window(10, 9, 5)
+    assert (s, e) == (7, 10)
+    assert T.temporal_window(4, 2, 1) == (2, 3, [1.0])
+    assert tap_ref.temporal_weights(10, 5, 5) == T.temporal_window(10, 5, 5)
+
+
+def test_oracle_truncates_like_the_reference():
+    t = torch.tensor([0.9999, 0.5, -0.2, 1.3]).view(1, 1, 2, 2).repeat(1, 3, 1, 1)
+    out = tap_ref.postprocess(t)
+    assert out[0, 0, 0] == 254 and out[0, 1, 0] == 127 and out[1, 0, 0] == 0 and out[1, 1, 0] == 255
+
+
+def test_unaccelerated_models_are_reported_unavailable():
+    d = T.TAPDenoiser(T.TAPDenoiseConfig(model=T.TAPModel.RESTORMER))
+    assert d.is_available() is False

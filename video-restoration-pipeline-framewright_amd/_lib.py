@@ -25,6 +25,9 @@ EXPORTS = [
     "fw_rrdbnet_create", "fw_rrdbnet_set_conv", "fw_rrdbnet_finalize", "fw_rrdbnet_upscale_u8",
     "fw_rrdbnet_workspace_bytes", "fw_rrdbnet_flops", "fw_rrdbnet_profile_enable", "fw_rrdbnet_profile_read",
     "fw_rrdbnet_destroy", "fw_pack_conv3x3", "fw_conv3x3_nhwc",
+    "fw_nafnet_create", "fw_nafnet_set_tensor", "fw_nafnet_finalize", "fw_nafnet_denoise_u8", "fw_nafnet_flops",
+    "fw_nafnet_destroy", "fw_u8_crop", "fw_tile_blend_accumulate", "fw_tile_blend_finish", "fw_temporal_average_u8",
+    "fw_strength_blend_u8",
 ]
 
 
@@ -77,6 +80,32 @@ def _declare(lib: C.CDLL) -> None:
                                     i32, C.c_long, i32, vp, vp]
 
 
+def _declare_tap(lib: C.CDLL) -> None:
+    vp, i32, f32, f64, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
+    lib.fw_nafnet_create.restype = i32
+    lib.fw_nafnet_create.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), i32, i32, C.POINTER(vp)]
+    lib.fw_nafnet_set_tensor.restype = i32
+    lib.fw_nafnet_set_tensor.argtypes = [vp, C.c_char_p, vp, sz]
+    lib.fw_nafnet_finalize.restype = i32
+    lib.fw_nafnet_finalize.argtypes = [vp]
+    lib.fw_nafnet_denoise_u8.restype = i32
+    lib.fw_nafnet_denoise_u8.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp]
+    lib.fw_nafnet_flops.restype = f64
+    lib.fw_nafnet_flops.argtypes = [vp, i32, i32]
+    lib.fw_nafnet_destroy.restype = i32
+    lib.fw_nafnet_destroy.argtypes = [vp]
+    lib.fw_u8_crop.restype = i32
+    lib.fw_u8_crop.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp]
+    lib.fw_tile_blend_accumulate.restype = i32
+    lib.fw_tile_blend_accumulate.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp]
+    lib.fw_tile_blend_finish.restype = i32
+    lib.fw_tile_blend_finish.argtypes = [vp, vp, i32, i32, vp, vp]
+    lib.fw_temporal_average_u8.restype = i32
+    lib.fw_temporal_average_u8.argtypes = [C.POINTER(vp), C.POINTER(f32), i32, sz, vp, vp]
+    lib.fw_strength_blend_u8.restype = i32
+    lib.fw_strength_blend_u8.argtypes = [vp, vp, f64, sz, vp, vp]
+
+
 def load() -> C.CDLL:
     """Load the shared library (once).  Raises FramewrightHipError when it is absent — build it with
     ``python __graft_entry__.py build`` (hipcc, gfx950)."""
@@ -99,6 +128,7 @@ def load() -> C.CDLL:
         except OSError as e:
             raise FramewrightHipError(FW_ERR_INTERNAL, f"cannot load {LIB_PATH}: {e}") from e
         _declare(lib)
+        _declare_tap(lib)
         _lib = lib
         return lib
 

@@ -21,6 +21,8 @@ LIB_DIR = PKG_DIR / "lib"
 OBJ_DIR = PKG_DIR / "build"
 LIB_PATH = LIB_DIR / "libframewright_hip.so"
 ARCH = "gfx950"
+# frame_ops.hip restates float32 numpy arithmetic bit for bit (a*b + c rounds twice): no FMA contraction there
+PER_FILE_FLAGS = {"frame_ops.hip": ["-ffp-contract=off"]}
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 
 
@@ -41,6 +43,7 @@ def _digest(paths: list[Path]) -> str:
         h.update(p.name.encode())
         h.update(p.read_bytes())
     h.update(" ".join(CXXFLAGS).encode())
+    h.update(repr(sorted(PER_FILE_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -61,7 +64,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
     def compile_one(src: Path) -> Path:
         obj = OBJ_DIR / (src.stem + ".o")
-        cmd = [cc, *CXXFLAGS, f"-I{INCLUDE}", f"-I{CSRC}", "-c", str(src), "-o", str(obj)]
+        cmd = [cc, *CXXFLAGS, *PER_FILE_FLAGS.get(src.name, []), f"-I{INCLUDE}", f"-I{CSRC}", "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -7,6 +7,9 @@
 // (basicsr RRDBNet.forward).
 #include "fw_internal.h"
 
+// The blend kernels below restate float32 numpy arithmetic bit for bit: a*b+c must round twice, so this translation
+// unit is compiled with -ffp-contract=off (build.py PER_FILE_FLAGS; hipcc's default is fast).
+
 namespace fw {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -87,6 +90,187 @@ void launch_u8_to_nhwc(DType dt, const uint8_t* in_bgr, int H, int W, void* out,
         if (unshuffle == 2) FW_LAUNCH(_Float16, 2); else FW_LAUNCH(_Float16, 1);
     }
 #undef FW_LAUNCH
+    FW_HIP_CHECK(hipGetLastError());
+}
+
+
+// ---- TAP (NAFNet) frame path ---------------------------------------------------------------------------------
+// uint8 BGR H x W x 3 -> typed [Hp][Wp][32] RGB/255 with zeros outside H x W (NAFNet.check_image_size zero pad,
+// SURVEY.md §A.3; pre-processing reference src/framewright/processors/tap_denoise.py:373-397).
+template <typename T>
+__global__ __launch_bounds__(256) void u8_to_nhwc_padded_kernel(const uint8_t* __restrict__ in, int H, int W, int Hp, int Wp,
+                                                                T* out) {
+    const long n = (long)Hp * Wp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / Wp), x = (int)(i - (long)y * Wp);
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (y < H && x < W) {
+            const uint8_t* px = in + ((size_t)y * W + x) * 3;
+            v[0] = px[2] / 255.0f;  // the reference divides (frame.astype(float32) / 255.0), it does not multiply by 1/255
+            v[1] = px[1] / 255.0f;
+            v[2] = px[0] / 255.0f;
+        }
+        uint4* o = reinterpret_cast<uint4*>(out + (size_t)i * 32);
+        o[0] = pack8<T>(v);
+        o[1] = make_uint4(0, 0, 0, 0);
+        o[2] = make_uint4(0, 0, 0, 0);
+        o[3] = make_uint4(0, 0, 0, 0);
+    }
+}
+
+void launch_u8_to_nhwc_padded(DType dt, const uint8_t* in_bgr, int H, int W, int Hp, int Wp, void* out, hipStream_t st) {
+    const long n = (long)Hp * Wp;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    if (dt == DT_BF16)
+        hipLaunchKernelGGL((u8_to_nhwc_padded_kernel<__bf16>), dim3(blocks), dim3(256), 0, st, in_bgr, H, W, Hp, Wp, (__bf16*)out);
+    else
+        hipLaunchKernelGGL((u8_to_nhwc_padded_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, in_bgr, H, W, Hp, Wp,
+                           (_Float16*)out);
+    FW_HIP_CHECK(hipGetLastError());
+}
+
+// out = ending(x) + inp, crop to H x W, then tap_denoise.py:399-415: np.clip(x * 255.0, 0, 255).astype(uint8)
+// (TRUNCATION, not rounding), RGB -> BGR.
+__global__ __launch_bounds__(256) void tap_post_kernel(const uint8_t* __restrict__ in_bgr, const float* __restrict__ rgb,
+                                                       int H, int W, int Wp, uint8_t* out_bgr, float* out_rgb) {
+    const long n = (long)H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W), x = (int)(i - (long)y * W);
+        const uint8_t* px = in_bgr + (size_t)i * 3;
+        const float* r = rgb + ((size_t)y * Wp + x) * 3;
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = r[c] + px[2 - c] / 255.0f;
+        if (out_rgb) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) out_rgb[(size_t)i * 3 + c] = v[c];
+        }
+        if (out_bgr) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) out_bgr[(size_t)i * 3 + (2 - c)] = (uint8_t)fminf(fmaxf(v[c] * 255.0f, 0.f), 255.f);
+        }
+    }
+}
+
+void launch_tap_post(const uint8_t* in_bgr, const float* rgb, int H, int W, int Wp, uint8_t* out_bgr, float* out_rgb,
+                     hipStream_t st) {
+    const long n = (long)H * W;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(tap_post_kernel, dim3(blocks), dim3(256), 0, st, in_bgr, rgb, H, W, Wp, out_bgr, out_rgb);
+    FW_HIP_CHECK(hipGetLastError());
+}
+
+// ---- K8: tile ramp blend, temporal weighted average, strength blend (uint8 truncation semantics) ------------------
+__global__ __launch_bounds__(256) void u8_crop_kernel(const uint8_t* __restrict__ src, int W, int y0, int x0, int th, int tw,
+                                                      uint8_t* dst) {
+    const long n = (long)th * tw * 3;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / (tw * 3)), rem = (int)(i - (long)y * tw * 3);
+        dst[i] = src[((size_t)(y0 + y) * W + x0) * 3 + rem];
+    }
+}
+
+void launch_u8_crop(const uint8_t* src, int W, int y0, int x0, int th, int tw, uint8_t* dst, hipStream_t st) {
+    const long n = (long)th * tw * 3;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(u8_crop_kernel, dim3(blocks), dim3(256), 0, st, src, W, y0, x0, th, tw, dst);
+    FW_HIP_CHECK(hipGetLastError());
+}
+
+// numpy.linspace(0, 1, n)[k] in float64: k * (1/(n-1)), last element exactly 1; linspace(0, 1, 1) == [0.]
+__device__ __forceinline__ double linspace01(int k, int n) {
+    if (n == 1) return 0.0;
+    return (k == n - 1) ? 1.0 : (double)k * (1.0 / (double)(n - 1));
+}
+
+// tap_denoise.py:461-486: tile_weight = ones; *= ramp on interior edges (float32 array *= float64 ramp, in the order
+// top, bottom, left, right); output += tile_result * tile_weight; weight += tile_weight (all float32)
+__global__ __launch_bounds__(256) void tile_blend_acc_kernel(float* acc, float* wsum, int W, const uint8_t* __restrict__ tile,
+                                                             int y0, int x0, int th, int tw, int ov, int top, int bottom,
+                                                             int left, int right) {
+    const long n = (long)th * tw;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / tw), x = (int)(i - (long)y * tw);
+        float wgt = 1.0f;
+        if (ov > 0) {
+            if (top && y < ov) wgt = (float)((double)wgt * linspace01(y, ov));
+            if (bottom && y >= th - ov) wgt = (float)((double)wgt * linspace01(th - 1 - y, ov));
+            if (left && x < ov) wgt = (float)((double)wgt * linspace01(x, ov));
+            if (right && x >= tw - ov) wgt = (float)((double)wgt * linspace01(tw - 1 - x, ov));
+        }
+        const size_t o = (size_t)(y0 + y) * W + (x0 + x);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[o * 3 + c] = __fadd_rn(acc[o * 3 + c], __fmul_rn((float)tile[(size_t)i * 3 + c], wgt));
+        wsum[o] = __fadd_rn(wsum[o], wgt);
+    }
+}
+
+void launch_tile_blend_acc(float* acc, float* wsum, int W, const uint8_t* tile, int y0, int x0, int th, int tw, int ov,
+                           int top, int bottom, int left, int right, hipStream_t st) {
+    const long n = (long)th * tw;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(tile_blend_acc_kernel, dim3(blocks), dim3(256), 0, st, acc, wsum, W, tile, y0, x0, th, tw, ov, top,
+                       bottom, left, right);
+    FW_HIP_CHECK(hipGetLastError());
+}
+
+// output = (output / max(weight, 1e-8)).astype(uint8)
+__global__ __launch_bounds__(256) void tile_blend_finish_kernel(const float* __restrict__ acc, const float* __restrict__ wsum,
+                                                                long npix, uint8_t* out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+        const float w = fmaxf(wsum[i], 1e-8f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[i * 3 + c] = (uint8_t)(int)__fdiv_rn(acc[i * 3 + c], w);
+    }
+}
+
+void launch_tile_blend_finish(const float* acc, const float* wsum, long npix, uint8_t* out, hipStream_t st) {
+    const int blocks = (int)((npix + 255) / 256 < 2048 ? (npix + 255) / 256 : 2048);
+    hipLaunchKernelGGL(tile_blend_finish_kernel, dim3(blocks), dim3(256), 0, st, acc, wsum, npix, out);
+    FW_HIP_CHECK(hipGetLastError());
+}
+
+// tap_denoise.py:521-534: result = zeros(float32); result += frame_k(float32) * w_k (w_k rounded to float32, product
+// and sum each rounded to float32, no fma); astype(uint8)
+struct TemporalArgs {
+    const uint8_t* frames[16];
+    float weights[16];
+    int count;
+};
+
+__global__ __launch_bounds__(256) void temporal_average_kernel(TemporalArgs a, long n, uint8_t* out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float r = 0.f;
+        for (int k = 0; k < a.count; ++k) r = __fadd_rn(r, __fmul_rn((float)a.frames[k][i], a.weights[k]));
+        out[i] = (uint8_t)(int)r;
+    }
+}
+
+void launch_temporal_average(const uint8_t* const* frames, const float* weights, int count, long n, uint8_t* out,
+                             hipStream_t st) {
+    if (count < 1 || count > 16) throw Error(1, "temporal_average: window must be 1..16 frames");
+    TemporalArgs a{};
+    a.count = count;
+    for (int k = 0; k < count; ++k) {
+        a.frames[k] = frames[k];
+        a.weights[k] = weights[k];
+    }
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(temporal_average_kernel, dim3(blocks), dim3(256), 0, st, a, n, out);
+    FW_HIP_CHECK(hipGetLastError());
+}
+
+// tap_denoise.py:614-618: blended = original * (1 - s) + denoised * s (float32, separate roundings); astype(uint8)
+__global__ __launch_bounds__(256) void strength_blend_kernel(const uint8_t* __restrict__ orig, const uint8_t* __restrict__ den,
+                                                             float one_minus_s, float s, long n, uint8_t* out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = (uint8_t)(int)__fadd_rn(__fmul_rn((float)orig[i], one_minus_s), __fmul_rn((float)den[i], s));
+}
+
+void launch_strength_blend(const uint8_t* orig, const uint8_t* den, float one_minus_s, float s, long n, uint8_t* out,
+                           hipStream_t st) {
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(strength_blend_kernel, dim3(blocks), dim3(256), 0, st, orig, den, one_minus_s, s, n, out);
     FW_HIP_CHECK(hipGetLastError());
 }
 

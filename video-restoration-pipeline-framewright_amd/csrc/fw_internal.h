@@ -66,6 +66,63 @@ size_t pack_conv3x3_weights(DType dt, const float* w, int cout, int cin, int cou
 void launch_u8_to_nhwc(DType dt, const uint8_t* in_bgr, int H, int W, void* out, int out_cstride,
                        int unshuffle, hipStream_t stream);
 
+// ---- NAFNet building blocks (nn_ops.hip) -------------------------------------------------------------
+enum PointwiseMode : int {
+    PW_STORE = 0,       // y = acc + bias -> typed and/or fp32 NHWC
+    PW_RESIDUAL = 1,    // y = res + (acc + bias) * chan_scale -> fp32 NHWC
+    PW_GATE = 2,        // SimpleGate fused: y[n] = (acc[n] + b[n]) * (acc[n + N/2] + b[n + N/2]) -> typed, N/2 channels
+    PW_SHUFFLE_UP = 3,  // 1x1 conv + PixelShuffle(2) + skip add -> fp32 NHWC at twice the resolution
+};
+
+struct PointwiseParams {
+    const void* a;         // [M][lda] operand-typed, or fp32 when a_f32
+    int a_f32;
+    long lda;              // elements per pixel row of a
+    long M;                // output pixels
+    int K;                 // contraction length (multiple of 32)
+    int gather2x2;         // 1: 2x2 stride-2 conv, k = (dy*2+dx)*Cin + ci, a is the full-resolution [Hin][Win][lda] map
+    int Win;               // gather2x2: input width; PW_SHUFFLE_UP: low-resolution width
+    int Cin;               // gather2x2: input channels (K = 4*Cin)
+    const float* a_scale;  // optional per-k scale applied while staging (SCA)
+    const void* wpk;       // pack_pointwise_weights
+    const float* bias;     // [32*N_tiles] or null
+    int N_tiles;           // cout / 32
+    int mode;
+    void* out_typed;
+    long ldo;
+    float* out_f32;
+    long ldf;
+    const float* res_f32;
+    const float* chan_scale;
+};
+
+void launch_pointwise(DType dt, const PointwiseParams& p, hipStream_t st);
+size_t pack_pointwise_weights(DType dt, const float* w, int cout, int K, uint16_t* dst);
+void launch_layernorm2d(DType dt, const float* x, long M, int C, const float* w, const float* b, void* out,
+                        hipStream_t st);
+int dwconv_blocks(int H, int W, int C);  // grid of the dwconv kernel = rows of its `partial` output
+void launch_dwconv3x3_gate(DType dt, const void* x, int H, int W, int C, const float* wdw, const float* bdw, void* out,
+                           float* partial /* [dwconv_blocks][C] or null */, hipStream_t st);
+void launch_sca(const float* partial, int nblocks, long HW, int C, const float* w, const float* b, float* s,
+                hipStream_t st);
+void launch_f32_to_planar(DType dt, const float* x, long M, int C, void* out, hipStream_t st);
+
+// ---- TAP frame path + K8 blend kernels (frame_ops.hip) ---------------------------------------------------
+void launch_u8_to_nhwc_padded(DType dt, const uint8_t* in_bgr, int H, int W, int Hp, int Wp, void* out, hipStream_t st);
+void launch_tap_post(const uint8_t* in_bgr, const float* rgb, int H, int W, int Wp, uint8_t* out_bgr, float* out_rgb,
+                     hipStream_t st);
+void launch_u8_crop(const uint8_t* src, int W, int y0, int x0, int th, int tw, uint8_t* dst, hipStream_t st);
+void launch_tile_blend_acc(float* acc, float* wsum, int W, const uint8_t* tile, int y0, int x0, int th, int tw, int ov,
+                           int top, int bottom, int left, int right, hipStream_t st);
+void launch_tile_blend_finish(const float* acc, const float* wsum, long npix, uint8_t* out, hipStream_t st);
+void launch_temporal_average(const uint8_t* const* frames, const float* weights, int count, long n, uint8_t* out,
+                             hipStream_t st);
+void launch_strength_blend(const uint8_t* orig, const uint8_t* den, float one_minus_s, float s, long n, uint8_t* out,
+                           hipStream_t st);
+
+// thread-local message returned by fw_last_error()
+std::string& last_error_ref();
+
 uint16_t f32_to_operand(DType dt, float f);
 float operand_to_f32(DType dt, uint16_t v);
 

@@ -1,0 +1,535 @@
+// NAFNet forward for the TAP temporal-denoise path on one MI355X: weights, workspace, launch sequencing.
+//
+// Reference call sites: src/framewright/processors/tap_denoise.py:335-364 (`NAFNet(img_channel=3, width=64,
+// middle_blk_num=12, enc_blk_nums=[2,2,4,8], dec_blk_nums=[2,2,2,2])`, weights under `params`/`state_dict`),
+// :373-415 (pre/post-processing: BGR->RGB, /255, ... np.clip(x*255, 0, 255).astype(uint8) — truncation), :458 (the
+// forward).  The network itself lives in a third-party package that is absent here; the architecture follows
+// SURVEY.md §A.3 and the oracle is oracle/nafnet_ref.py ("parity vs upstream unpinned").
+#include <map>
+#include <mutex>
+#include <memory>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include "fw_internal.h"
+#include "../../include/framewright_hip.h"
+
+using namespace fw;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct Block {
+    int c = 0;
+    // device weights
+    DevBuf n1w, n1b, n2w, n2b, beta, gamma;            // fp32 [c]
+    DevBuf w1, b1, w3, b3, w4, b4, w5, b5;             // packed pointwise weights + fp32 biases
+    DevBuf wdw, bdw;                                   // depthwise fp32 [2c][9], [2c]
+    DevBuf wsca, bsca;                                 // fp32 [c][c], [c]
+    unsigned have = 0;                                 // bit per tensor
+};
+constexpr unsigned BLOCK_ALL = (1u << 18) - 1;
+
+struct Level {
+    DevBuf w, b;  // down: packed [2c][4c] + bias[2c]; up: packed [2c_hi][c_hi] (no bias)
+    bool have_w = false, have_b = false;
+};
+
+}  // namespace
+
+struct fw_nafnet {
+    int device = 0;
+    DType dt = DT_BF16;
+    int width = 64, middle = 12;
+    int nlev = 4;
+    int enc[8] = {0}, dec[8] = {0};
+    std::mutex mu;
+    std::vector<std::vector<Block>> encoders, decoders;
+    std::vector<Block> middle_blks;
+    std::vector<Level> downs, ups;
+    DevBuf intro_w, intro_b, ending_w, ending_b;
+    bool have_intro_w = false, have_intro_b = false, have_end_w = false, have_end_b = false;
+    DevBuf ws;
+};
+
+namespace {
+
+int fail(int code, const std::string& m) {
+    fw::last_error_ref() = m;
+    return code;
+}
+template <typename F>
+int guarded(F&& f) {
+    try {
+        f();
+        return FW_OK;
+    } catch (const fw::Error& e) {
+        return fail(e.code, e.what());
+    } catch (const std::bad_alloc&) {
+        return fail(FW_ERR_OOM, "host out of memory");
+    } catch (const std::exception& e) {
+        return fail(FW_ERR_INTERNAL, e.what());
+    }
+}
+
+struct DevGuard {
+    int prev = -1;
+    explicit DevGuard(int d) {
+        FW_HIP_CHECK(hipGetDevice(&prev));
+        if (prev != d) FW_HIP_CHECK(hipSetDevice(d)); else prev = -1;
+    }
+    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+void upload(DevBuf& b, const void* src, size_t bytes) {
+    b.release();
+    FW_HIP_CHECK(hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    FW_HIP_CHECK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+}
+
+void upload_pointwise(DType dt, DevBuf& b, const float* w, int cout, int K) {
+    std::vector<uint16_t> pk(pack_pointwise_weights(dt, nullptr, cout, K, nullptr));
+    pack_pointwise_weights(dt, w, cout, K, pk.data());
+    upload(b, pk.data(), pk.size() * 2);
+}
+
+void upload_conv3(DType dt, DevBuf& b, const float* w, int cout, int cin) {
+    const int ct = (cout + 31) / 32, ch = (cin + 31) / 32;
+    std::vector<uint16_t> pk(pack_conv3x3_weights(dt, nullptr, cout, cin, ct, ch, nullptr));
+    pack_conv3x3_weights(dt, w, cout, cin, ct, ch, pk.data());
+    upload(b, pk.data(), pk.size() * 2);
+}
+
+void upload_padded_bias(DevBuf& b, const float* src, int n, int padded) {
+    std::vector<float> v(padded, 0.f);
+    for (int i = 0; i < n; ++i) v[i] = src[i];
+    upload(b, v.data(), v.size() * 4);
+}
+
+// which block does "encoders.1.0." / "middle_blks.3." / "decoders.2.1." name?
+Block* find_block(fw_nafnet* n, const std::string& key, std::string* rest) {
+    int a = -1, b = -1, used = 0;
+    if (sscanf(key.c_str(), "encoders.%d.%d.%n", &a, &b, &used) == 2 && used > 0) {
+        if (a < 0 || a >= n->nlev || b < 0 || b >= (int)n->encoders[a].size()) return nullptr;
+        *rest = key.substr(used);
+        return &n->encoders[a][b];
+    }
+    if (sscanf(key.c_str(), "decoders.%d.%d.%n", &a, &b, &used) == 2 && used > 0) {
+        if (a < 0 || a >= n->nlev || b < 0 || b >= (int)n->decoders[a].size()) return nullptr;
+        *rest = key.substr(used);
+        return &n->decoders[a][b];
+    }
+    if (sscanf(key.c_str(), "middle_blks.%d.%n", &a, &used) == 1 && used > 0) {
+        if (a < 0 || a >= (int)n->middle_blks.size()) return nullptr;
+        *rest = key.substr(used);
+        return &n->middle_blks[a];
+    }
+    return nullptr;
+}
+
+void need(size_t got, size_t want, const std::string& key) {
+    if (got != want)
+        throw Error(FW_ERR_INVALID, "fw_nafnet_set_tensor: '" + key + "' has " + std::to_string(got) + " elements, expected " +
+                                        std::to_string(want));
+}
+
+void set_block_tensor(fw_nafnet* n, Block& bl, const std::string& name, const std::string& key, const float* d,
+                      size_t numel) {
+    const int c = bl.c;
+    auto mark = [&](int bit) { bl.have |= 1u << bit; };
+    if (name == "norm1.weight") { need(numel, c, key); upload(bl.n1w, d, c * 4); mark(0); }
+    else if (name == "norm1.bias") { need(numel, c, key); upload(bl.n1b, d, c * 4); mark(1); }
+    else if (name == "norm2.weight") { need(numel, c, key); upload(bl.n2w, d, c * 4); mark(2); }
+    else if (name == "norm2.bias") { need(numel, c, key); upload(bl.n2b, d, c * 4); mark(3); }
+    else if (name == "beta") { need(numel, c, key); upload(bl.beta, d, c * 4); mark(4); }
+    else if (name == "gamma") { need(numel, c, key); upload(bl.gamma, d, c * 4); mark(5); }
+    else if (name == "conv1.weight") { need(numel, (size_t)2 * c * c, key); upload_pointwise(n->dt, bl.w1, d, 2 * c, c); mark(6); }
+    else if (name == "conv1.bias") { need(numel, 2 * c, key); upload(bl.b1, d, 2 * c * 4); mark(7); }
+    else if (name == "conv2.weight") { need(numel, (size_t)2 * c * 9, key); upload(bl.wdw, d, (size_t)2 * c * 9 * 4); mark(8); }
+    else if (name == "conv2.bias") { need(numel, 2 * c, key); upload(bl.bdw, d, 2 * c * 4); mark(9); }
+    else if (name == "conv3.weight") { need(numel, (size_t)c * c, key); upload_pointwise(n->dt, bl.w3, d, c, c); mark(10); }
+    else if (name == "conv3.bias") { need(numel, c, key); upload(bl.b3, d, c * 4); mark(11); }
+    else if (name == "conv4.weight") { need(numel, (size_t)2 * c * c, key); upload_pointwise(n->dt, bl.w4, d, 2 * c, c); mark(12); }
+    else if (name == "conv4.bias") { need(numel, 2 * c, key); upload(bl.b4, d, 2 * c * 4); mark(13); }
+    else if (name == "conv5.weight") { need(numel, (size_t)c * c, key); upload_pointwise(n->dt, bl.w5, d, c, c); mark(14); }
+    else if (name == "conv5.bias") { need(numel, c, key); upload(bl.b5, d, c * 4); mark(15); }
+    else if (name == "sca.1.weight") { need(numel, (size_t)c * c, key); upload(bl.wsca, d, (size_t)c * c * 4); mark(16); }
+    else if (name == "sca.1.bias") { need(numel, c, key); upload(bl.bsca, d, c * 4); mark(17); }
+    else throw Error(FW_ERR_INVALID, "fw_nafnet_set_tensor: unknown tensor '" + key + "'");
+}
+
+struct Plan {
+    int Hp, Wp;
+    size_t in_u8, out_u8, img32, S[8], T1, T2, T3, csum, sca, cat64, rgb, total;
+};
+
+size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+Plan make_plan(const fw_nafnet* n, int H, int W) {
+    Plan p{};
+    const int mult = 1 << n->nlev;
+    p.Hp = (H + mult - 1) / mult * mult;
+    p.Wp = (W + mult - 1) / mult * mult;
+    const size_t M0 = (size_t)p.Hp * p.Wp;
+    size_t o = 0;
+    auto take = [&](size_t b) { size_t at = o; o += up256(b); return at; };
+    p.in_u8 = take((size_t)H * W * 3);
+    p.out_u8 = take((size_t)H * W * 3);
+    p.img32 = take(M0 * 32 * 2);
+    for (int l = 0; l <= n->nlev; ++l) p.S[l] = take((M0 >> (2 * l)) * ((size_t)n->width << l) * 4);
+    p.T1 = take(M0 * n->width * 2);
+    p.T2 = take(M0 * n->width * 2 * 2);
+    p.T3 = take(M0 * n->width * 2);
+    p.csum = take((size_t)1024 * 1024 * 4);  // dwconv partial sums [<=1024 blocks][<=1024 channels]
+    p.sca = take(4096);
+    p.cat64 = take(M0 * n->width * 2);
+    p.rgb = take(M0 * 3 * 4);
+    p.total = o;
+    return p;
+}
+
+void run_block(fw_nafnet* n, const Block& b, float* S, int H, int W, char* ws, const Plan& pl, hipStream_t st) {
+    const int c = b.c;
+    const long M = (long)H * W;
+    void* T1 = ws + pl.T1;
+    void* T2 = ws + pl.T2;
+    void* T3 = ws + pl.T3;
+    float* csum = (float*)(ws + pl.csum);
+    float* sca = (float*)(ws + pl.sca);
+    // x = conv1(norm1(inp))
+    launch_layernorm2d(n->dt, S, M, c, (const float*)b.n1w.p, (const float*)b.n1b.p, T1, st);
+    PointwiseParams p{};
+    p.a = T1; p.lda = c; p.M = M; p.K = c; p.wpk = b.w1.p; p.bias = (const float*)b.b1.p; p.N_tiles = 2 * c / 32;
+    p.mode = PW_STORE; p.out_typed = T2; p.ldo = 2 * c;
+    launch_pointwise(n->dt, p, st);
+    // x = SimpleGate(conv2(x)); pooled sums for SCA
+    launch_dwconv3x3_gate(n->dt, T2, H, W, c, (const float*)b.wdw.p, (const float*)b.bdw.p, T3, csum, st);
+    launch_sca(csum, dwconv_blocks(H, W, c), M, c, (const float*)b.wsca.p, (const float*)b.bsca.p, sca, st);
+    // y = inp + conv3(x * sca) * beta
+    p = PointwiseParams{};
+    p.a = T3; p.lda = c; p.M = M; p.K = c; p.a_scale = sca; p.wpk = b.w3.p; p.bias = (const float*)b.b3.p; p.N_tiles = c / 32;
+    p.mode = PW_RESIDUAL; p.out_f32 = S; p.res_f32 = S; p.ldf = c; p.chan_scale = (const float*)b.beta.p;
+    launch_pointwise(n->dt, p, st);
+    // x = conv5(SimpleGate(conv4(norm2(y)))) ; out = y + x * gamma
+    launch_layernorm2d(n->dt, S, M, c, (const float*)b.n2w.p, (const float*)b.n2b.p, T1, st);
+    p = PointwiseParams{};
+    p.a = T1; p.lda = c; p.M = M; p.K = c; p.wpk = b.w4.p; p.bias = (const float*)b.b4.p; p.N_tiles = 2 * c / 32;
+    p.mode = PW_GATE; p.out_typed = T3; p.ldo = c;
+    launch_pointwise(n->dt, p, st);
+    p = PointwiseParams{};
+    p.a = T3; p.lda = c; p.M = M; p.K = c; p.wpk = b.w5.p; p.bias = (const float*)b.b5.p; p.N_tiles = c / 32;
+    p.mode = PW_RESIDUAL; p.out_f32 = S; p.res_f32 = S; p.ldf = c; p.chan_scale = (const float*)b.gamma.p;
+    launch_pointwise(n->dt, p, st);
+}
+
+void forward(fw_nafnet* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, float* d_rgb, hipStream_t st) {
+    const Plan pl = make_plan(n, H, W);
+    char* ws = (char*)n->ws.p;
+    const int Hp = pl.Hp, Wp = pl.Wp;
+    const long M0 = (long)Hp * Wp;
+    float* S[8];
+    for (int l = 0; l <= n->nlev; ++l) S[l] = (float*)(ws + pl.S[l]);
+
+    // pre-process (tap_denoise.py:373-397) + zero pad to a multiple of 2^levels (NAFNet.check_image_size)
+    launch_u8_to_nhwc_padded(n->dt, d_in, H, W, Hp, Wp, ws + pl.img32, st);
+    // intro 3x3 (3 -> width), fp32 NHWC residual stream
+    {
+        ConvParams p{};
+        p.in = ws + pl.img32; p.in_cstride = 32; p.in_pstride = 32; p.H = Hp; p.W = Wp; p.cin_chunks = 1;
+        p.wpk = n->intro_w.p; p.bias = (const float*)n->intro_b.p; p.out_f32 = S[0]; p.s1 = p.s2 = 1.f;
+        launch_conv3x3(n->dt, n->width / 32, EPI_STORE, p, st);
+    }
+    int h = Hp, w = Wp;
+    for (int l = 0; l < n->nlev; ++l) {
+        for (const Block& b : n->encoders[l]) run_block(n, b, S[l], h, w, ws, pl, st);
+        // down: 2x2 stride 2, c -> 2c
+        const int c = n->width << l;
+        PointwiseParams p{};
+        p.a = S[l]; p.a_f32 = 1; p.lda = c; p.M = (long)(h / 2) * (w / 2); p.K = 4 * c; p.gather2x2 = 1; p.Win = w; p.Cin = c;
+        p.wpk = n->downs[l].w.p; p.bias = (const float*)n->downs[l].b.p; p.N_tiles = 2 * c / 32; p.mode = PW_STORE;
+        p.out_f32 = S[l + 1]; p.ldf = 2 * c;
+        launch_pointwise(n->dt, p, st);
+        h /= 2;
+        w /= 2;
+    }
+    for (const Block& b : n->middle_blks) run_block(n, b, S[n->nlev], h, w, ws, pl, st);
+    for (int i = 0; i < n->nlev; ++i) {
+        const int l = n->nlev - 1 - i;          // target level
+        const int chi = n->width << (l + 1);    // channels of the coarser level
+        // x = PixelShuffle(conv1x1(x)) + skip, written in place into the skip buffer
+        PointwiseParams p{};
+        p.a = S[l + 1]; p.a_f32 = 1; p.lda = chi; p.M = (long)h * w; p.K = chi; p.Win = w;
+        p.wpk = n->ups[i].w.p; p.bias = nullptr; p.N_tiles = 2 * chi / 32; p.mode = PW_SHUFFLE_UP;
+        p.out_f32 = S[l]; p.res_f32 = S[l]; p.ldf = chi / 2;
+        launch_pointwise(n->dt, p, st);
+        h *= 2;
+        w *= 2;
+        for (const Block& b : n->decoders[i]) run_block(n, b, S[l], h, w, ws, pl, st);
+    }
+    // ending 3x3 (width -> 3) + inp, crop, quantise (tap_denoise.py:399-415)
+    launch_f32_to_planar(n->dt, S[0], M0, n->width, ws + pl.cat64, st);
+    {
+        ConvParams p{};
+        p.in = ws + pl.cat64; p.in_cstride = 32; p.in_pstride = M0 * 32; p.H = Hp; p.W = Wp; p.cin_chunks = n->width / 32;
+        p.wpk = n->ending_w.p; p.bias = (const float*)n->ending_b.p; p.out_rgb = (float*)(ws + pl.rgb); p.img_H = Hp;
+        p.img_W = Wp; p.s1 = p.s2 = 1.f;
+        launch_conv3x3(n->dt, 1, EPI_IMAGE, p, st);
+    }
+    launch_tap_post(d_in, (const float*)(ws + pl.rgb), H, W, Wp, d_out, d_rgb, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int fw_nafnet_create(int device_id, int width, int middle_blk_num, const int* enc_blk_nums, const int* dec_blk_nums,
+                     int num_levels, int dtype, fw_nafnet** out) {
+    if (!out || !enc_blk_nums || !dec_blk_nums) return fail(FW_ERR_INVALID, "fw_nafnet_create: NULL argument");
+    *out = nullptr;
+    if ((width != 32 && width != 64) || (width << num_levels) > 1024)
+        return fail(FW_ERR_INVALID, "fw_nafnet_create: width must be 32 or 64 with width*2^levels <= 1024");
+    if (num_levels < 1 || num_levels > 6 || middle_blk_num < 0 || middle_blk_num > 64)
+        return fail(FW_ERR_INVALID, "fw_nafnet_create: bad level/block counts");
+    if (dtype != FW_DTYPE_BF16 && dtype != FW_DTYPE_F16) return fail(FW_ERR_INVALID, "fw_nafnet_create: bad dtype");
+    return guarded([&] {
+        int nd = 0;
+        FW_HIP_CHECK(hipGetDeviceCount(&nd));
+        if (device_id < 0 || device_id >= nd) throw Error(FW_ERR_INVALID, "fw_nafnet_create: no such device");
+        auto n = std::make_unique<fw_nafnet>();
+        n->device = device_id;
+        n->dt = (DType)dtype;
+        n->width = width;
+        n->middle = middle_blk_num;
+        n->nlev = num_levels;
+        n->encoders.resize(num_levels);
+        n->decoders.resize(num_levels);
+        n->downs.resize(num_levels);
+        n->ups.resize(num_levels);
+        for (int l = 0; l < num_levels; ++l) {
+            if (enc_blk_nums[l] < 0 || enc_blk_nums[l] > 64 || dec_blk_nums[l] < 0 || dec_blk_nums[l] > 64)
+                throw Error(FW_ERR_INVALID, "fw_nafnet_create: bad block count");
+            n->enc[l] = enc_blk_nums[l];
+            n->dec[l] = dec_blk_nums[l];
+            n->encoders[l].resize(enc_blk_nums[l]);
+            for (auto& b : n->encoders[l]) b.c = width << l;
+            // decoders[i] works at level nlev-1-i
+            n->decoders[l].resize(dec_blk_nums[l]);
+            for (auto& b : n->decoders[l]) b.c = width << (num_levels - 1 - l);
+        }
+        n->middle_blks.resize(middle_blk_num);
+        for (auto& b : n->middle_blks) b.c = width << num_levels;
+        *out = n.release();
+    });
+}
+
+int fw_nafnet_set_tensor(fw_nafnet* n, const char* key_c, const float* data, size_t numel) {
+    if (!n || !key_c || !data) return fail(FW_ERR_INVALID, "fw_nafnet_set_tensor: NULL argument");
+    return guarded([&] {
+        std::lock_guard<std::mutex> lk(n->mu);
+        DevGuard dg(n->device);
+        const std::string key(key_c);
+        const int w = n->width;
+        if (key == "intro.weight") { need(numel, (size_t)w * 3 * 9, key); upload_conv3(n->dt, n->intro_w, data, w, 3); n->have_intro_w = true; return; }
+        if (key == "intro.bias") { need(numel, w, key); upload_padded_bias(n->intro_b, data, w, 64 > w ? 64 : w); n->have_intro_b = true; return; }
+        if (key == "ending.weight") { need(numel, (size_t)3 * w * 9, key); upload_conv3(n->dt, n->ending_w, data, 3, w); n->have_end_w = true; return; }
+        if (key == "ending.bias") { need(numel, 3, key); upload_padded_bias(n->ending_b, data, 3, 32); n->have_end_b = true; return; }
+        int a = -1, used = 0;
+        if (sscanf(key_c, "downs.%d.%n", &a, &used) == 1 && used > 0) {
+            if (a < 0 || a >= n->nlev) throw Error(FW_ERR_INVALID, "fw_nafnet_set_tensor: bad level in '" + key + "'");
+            const int c = w << a;
+            const std::string rest = key.substr(used);
+            if (rest == "weight") {
+                need(numel, (size_t)2 * c * c * 4, key);
+                // [2c][c][2][2] -> [2c][k = (dy*2+dx)*c + ci]
+                std::vector<float> r((size_t)2 * c * 4 * c);
+                for (int co = 0; co < 2 * c; ++co)
+                    for (int ci = 0; ci < c; ++ci)
+                        for (int s = 0; s < 4; ++s) r[(size_t)co * 4 * c + (size_t)s * c + ci] = data[((size_t)co * c + ci) * 4 + s];
+                upload_pointwise(n->dt, n->downs[a].w, r.data(), 2 * c, 4 * c);
+                n->downs[a].have_w = true;
+            } else if (rest == "bias") {
+                need(numel, 2 * c, key);
+                upload(n->downs[a].b, data, (size_t)2 * c * 4);
+                n->downs[a].have_b = true;
+            } else throw Error(FW_ERR_INVALID, "fw_nafnet_set_tensor: unknown tensor '" + key + "'");
+            return;
+        }
+        if (sscanf(key_c, "ups.%d.0.%n", &a, &used) == 1 && used > 0) {
+            if (a < 0 || a >= n->nlev) throw Error(FW_ERR_INVALID, "fw_nafnet_set_tensor: bad level in '" + key + "'");
+            if (key.substr(used) != "weight") throw Error(FW_ERR_INVALID, "fw_nafnet_set_tensor: unknown tensor '" + key + "'");
+            const int chi = w << (n->nlev - a);  // ups[a] takes the channels of level nlev-a
+            need(numel, (size_t)2 * chi * chi, key);
+            // conv out channel co*4 + sub  ->  kernel order sub*(chi/2) + co     (PixelShuffle(2) un-interleaved)
+            const int cup = chi / 2;
+            std::vector<float> r((size_t)2 * chi * chi);
+            for (int co = 0; co < cup; ++co)
+                for (int s = 0; s < 4; ++s)
+                    for (int k = 0; k < chi; ++k) r[((size_t)s * cup + co) * chi + k] = data[((size_t)co * 4 + s) * chi + k];
+            upload_pointwise(n->dt, n->ups[a].w, r.data(), 2 * chi, chi);
+            n->ups[a].have_w = true;
+            return;
+        }
+        std::string rest;
+        Block* bl = find_block(n, key, &rest);
+        if (!bl) throw Error(FW_ERR_INVALID, "fw_nafnet_set_tensor: unknown tensor '" + key + "'");
+        set_block_tensor(n, *bl, rest, key, data, numel);
+    });
+}
+
+int fw_nafnet_finalize(fw_nafnet* n) {
+    if (!n) return fail(FW_ERR_INVALID, "fw_nafnet_finalize: NULL");
+    std::lock_guard<std::mutex> lk(n->mu);
+    if (!n->have_intro_w || !n->have_intro_b || !n->have_end_w || !n->have_end_b)
+        return fail(FW_ERR_INVALID, "fw_nafnet_finalize: intro/ending missing");
+    for (int l = 0; l < n->nlev; ++l) {
+        if (!n->downs[l].have_w || !n->downs[l].have_b) return fail(FW_ERR_INVALID, "fw_nafnet_finalize: missing downs." + std::to_string(l));
+        if (!n->ups[l].have_w) return fail(FW_ERR_INVALID, "fw_nafnet_finalize: missing ups." + std::to_string(l));
+        for (size_t j = 0; j < n->encoders[l].size(); ++j)
+            if (n->encoders[l][j].have != BLOCK_ALL)
+                return fail(FW_ERR_INVALID, "fw_nafnet_finalize: incomplete encoders." + std::to_string(l) + "." + std::to_string(j));
+        for (size_t j = 0; j < n->decoders[l].size(); ++j)
+            if (n->decoders[l][j].have != BLOCK_ALL)
+                return fail(FW_ERR_INVALID, "fw_nafnet_finalize: incomplete decoders." + std::to_string(l) + "." + std::to_string(j));
+    }
+    for (size_t j = 0; j < n->middle_blks.size(); ++j)
+        if (n->middle_blks[j].have != BLOCK_ALL) return fail(FW_ERR_INVALID, "fw_nafnet_finalize: incomplete middle_blks." + std::to_string(j));
+    return FW_OK;
+}
+
+int fw_nafnet_denoise_u8(fw_nafnet* n, const uint8_t* in_bgr, int in_loc, int H, int W, uint8_t* out_bgr, int out_loc,
+                         float* out_rgb_f32, void* stream) {
+    if (!n || !in_bgr) return fail(FW_ERR_INVALID, "fw_nafnet_denoise_u8: NULL argument");
+    if (!out_bgr && !out_rgb_f32) return fail(FW_ERR_INVALID, "fw_nafnet_denoise_u8: no output requested");
+    if (H < 1 || W < 1 || H > 16384 || W > 16384) return fail(FW_ERR_INVALID, "fw_nafnet_denoise_u8: bad frame size");
+    if ((in_loc != FW_HOST && in_loc != FW_DEVICE) || (out_loc != FW_HOST && out_loc != FW_DEVICE))
+        return fail(FW_ERR_INVALID, "fw_nafnet_denoise_u8: bad buffer location");
+    int rc = fw_nafnet_finalize(n);
+    if (rc != FW_OK) return rc;
+    return guarded([&] {
+        std::lock_guard<std::mutex> lk(n->mu);
+        DevGuard dg(n->device);
+        hipStream_t st = (hipStream_t)stream;
+        const Plan pl = make_plan(n, H, W);
+        if (n->ws.bytes < pl.total) {
+            FW_HIP_CHECK(hipDeviceSynchronize());
+            n->ws.release();
+            FW_HIP_CHECK(hipMalloc(&n->ws.p, pl.total));
+            n->ws.bytes = pl.total;
+        }
+        const size_t bytes = (size_t)H * W * 3;
+        const uint8_t* d_in = in_bgr;
+        if (in_loc == FW_HOST) {
+            uint8_t* stg = (uint8_t*)n->ws.p + pl.in_u8;
+            FW_HIP_CHECK(hipMemcpyAsync(stg, in_bgr, bytes, hipMemcpyHostToDevice, st));
+            d_in = stg;
+        }
+        uint8_t* d_out = out_bgr;
+        if (out_bgr && out_loc == FW_HOST) d_out = (uint8_t*)n->ws.p + pl.out_u8;
+        forward(n, d_in, H, W, d_out, out_rgb_f32, st);
+        if (out_bgr && out_loc == FW_HOST) {
+            FW_HIP_CHECK(hipMemcpyAsync(out_bgr, d_out, bytes, hipMemcpyDeviceToHost, st));
+            FW_HIP_CHECK(hipStreamSynchronize(st));
+        }
+    });
+}
+
+double fw_nafnet_flops(const fw_nafnet* n, int H, int W) {
+    if (!n || H < 1 || W < 1) return 0.0;
+    const int mult = 1 << n->nlev;
+    const double Hp = (H + mult - 1) / mult * mult, Wp = (W + mult - 1) / mult * mult;
+    double mac = 0;
+    auto block = [](double c) { return c * 2 * c + 2 * c * 9 + c * c + c * 2 * c + c * c; };  // per pixel (SCA mat-vec ignored)
+    double px = Hp * Wp;
+    mac += px * 9 * 3 * n->width;
+    for (int l = 0; l < n->nlev; ++l) {
+        const double c = (double)(n->width << l);
+        mac += px * block(c) * n->enc[l];
+        mac += px / 4 * 4 * c * 2 * c;  // down
+        px /= 4;
+    }
+    mac += px * block((double)(n->width << n->nlev)) * n->middle;
+    for (int i = 0; i < n->nlev; ++i) {
+        const double chi = (double)(n->width << (n->nlev - i));
+        mac += px * chi * 2 * chi;  // up 1x1
+        px *= 4;
+        mac += px * block(chi / 2) * n->dec[i];
+    }
+    mac += px * 9 * n->width * 3;
+    return 2.0 * mac;
+}
+
+// ---- K8: blend kernels of the TAP driver (tap_denoise.py:417-534, :614-618) ---------------------------------------
+int fw_u8_crop(const uint8_t* src, int height, int width, int y0, int x0, int th, int tw, uint8_t* dst, void* stream) {
+    if (!src || !dst || th < 1 || tw < 1 || y0 < 0 || x0 < 0 || y0 + th > height || x0 + tw > width)
+        return fail(FW_ERR_INVALID, "fw_u8_crop: window outside the frame");
+    return guarded([&] { launch_u8_crop(src, width, y0, x0, th, tw, dst, (hipStream_t)stream); });
+}
+
+int fw_tile_blend_accumulate(float* acc, float* wsum, int height, int width, const uint8_t* tile, int y0, int x0, int th,
+                             int tw, int overlap, void* stream) {
+    if (!acc || !wsum || !tile || th < 1 || tw < 1 || y0 < 0 || x0 < 0 || y0 + th > height || x0 + tw > width || overlap < 0 ||
+        overlap > th || overlap > tw)
+        return fail(FW_ERR_INVALID, "fw_tile_blend_accumulate: bad tile geometry");
+    return guarded([&] {
+        launch_tile_blend_acc(acc, wsum, width, tile, y0, x0, th, tw, overlap, y0 > 0, y0 + th < height, x0 > 0,
+                              x0 + tw < width, (hipStream_t)stream);
+    });
+}
+
+int fw_tile_blend_finish(const float* acc, const float* wsum, int height, int width, uint8_t* out, void* stream) {
+    if (!acc || !wsum || !out || height < 1 || width < 1) return fail(FW_ERR_INVALID, "fw_tile_blend_finish: bad argument");
+    return guarded([&] { launch_tile_blend_finish(acc, wsum, (long)height * width, out, (hipStream_t)stream); });
+}
+
+int fw_temporal_average_u8(const uint8_t* const* frames, const float* weights, int count, size_t nbytes, uint8_t* out,
+                           void* stream) {
+    if (!frames || !weights || !out || count < 1 || count > 16) return fail(FW_ERR_INVALID, "fw_temporal_average_u8: bad argument");
+    for (int k = 0; k < count; ++k)
+        if (!frames[k]) return fail(FW_ERR_INVALID, "fw_temporal_average_u8: NULL frame");
+    return guarded([&] { launch_temporal_average(frames, weights, count, (long)nbytes, out, (hipStream_t)stream); });
+}
+
+int fw_strength_blend_u8(const uint8_t* original, const uint8_t* denoised, double strength, size_t nbytes, uint8_t* out,
+                         void* stream) {
+    if (!original || !denoised || !out || !(strength >= 0.0 && strength <= 1.0))
+        return fail(FW_ERR_INVALID, "fw_strength_blend_u8: bad argument");
+    // (1 - s) is formed in double like the reference's Python float arithmetic, then rounded once to float32
+    const float oms = (float)(1.0 - strength);
+    const float sf = (float)strength;
+    return guarded([&] { launch_strength_blend(original, denoised, oms, sf, (long)nbytes, out, (hipStream_t)stream); });
+}
+
+int fw_nafnet_destroy(fw_nafnet* n) {
+    if (!n) return FW_OK;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(n->device);
+    (void)hipDeviceSynchronize();
+    auto free_block = [](Block& b) {
+        for (DevBuf* d : {&b.n1w, &b.n1b, &b.n2w, &b.n2b, &b.beta, &b.gamma, &b.w1, &b.b1, &b.w3, &b.b3, &b.w4, &b.b4, &b.w5,
+                          &b.b5, &b.wdw, &b.bdw, &b.wsca, &b.bsca})
+            d->release();
+    };
+    for (auto& v : n->encoders) for (auto& b : v) free_block(b);
+    for (auto& v : n->decoders) for (auto& b : v) free_block(b);
+    for (auto& b : n->middle_blks) free_block(b);
+    for (auto& l : n->downs) { l.w.release(); l.b.release(); }
+    for (auto& l : n->ups) { l.w.release(); l.b.release(); }
+    n->intro_w.release(); n->intro_b.release(); n->ending_w.release(); n->ending_b.release();
+    n->ws.release();
+    if (prev >= 0) (void)hipSetDevice(prev);
+    delete n;
+    return FW_OK;
+}
+
+}  // extern "C"

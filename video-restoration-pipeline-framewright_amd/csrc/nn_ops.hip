@@ -1,0 +1,547 @@
+// NAFNet building blocks (kernel set K6 of SURVEY.md §8a) for the TAP temporal-denoise path.
+//
+// The reference runs these through third-party `basicsr.archs.nafnet_arch.NAFNet` (call site reference
+// src/framewright/processors/tap_denoise.py:335-364, forward at :458); the architecture restated here is the one
+// recorded in SURVEY.md §A.3 (NAFBlock: LayerNorm2d -> 1x1 -> depthwise 3x3 -> SimpleGate -> SCA -> 1x1 -> beta
+// residual -> LayerNorm2d -> 1x1 -> SimpleGate -> 1x1 -> gamma residual; 2x2/s2 down, 1x1 + PixelShuffle up).
+//
+// Data layout: the residual stream is fp32 NHWC ([pixel][C]); everything that feeds an MFMA is operand-typed NHWC.
+//   * pointwise_mfma_kernel : 1x1 conv / 2x2-s2 conv / 1x1+PixelShuffle as one MFMA GEMM D[cout][pixel], pixel on the
+//                             lane (same orientation as conv3x3_mfma.hip), fused SimpleGate / residual epilogues.
+//   * layernorm2d_kernel    : per-pixel LayerNorm over channels (HBM-bound, one wave per pixel, shuffles).
+//   * dwconv3x3_gate_kernel : depthwise 3x3 + SimpleGate + per-channel partial sums for SCA (HBM-bound).
+//   * sca_kernel            : global-average-pool finish + 1x1 conv (a CxC mat-vec).
+#include "fw_internal.h"
+
+namespace fw {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct Tr;
+template <>
+struct Tr<__bf16> {
+    using v8 = bf16x8;
+    using v4 = bf16x4;
+    static __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
+                                                       0, 0, 0);
+    }
+};
+template <>
+struct Tr<_Float16> {
+    using v8 = f16x8;
+    using v4 = f16x4;
+    static __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0,
+                                                      0, 0);
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ uint4 pack8f(const float* v) {
+    typename Tr<T>::v8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (T)v[i];
+    return __builtin_bit_cast(uint4, o);
+}
+template <typename T>
+__device__ __forceinline__ void unpack8f(uint4 u, float* v) {
+    typename Tr<T>::v8 o = __builtin_bit_cast(typename Tr<T>::v8, u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)o[i];
+}
+template <typename T>
+__device__ __forceinline__ uint2 pack4f(float a, float b, float c, float d) {
+    typename Tr<T>::v4 v = {(T)a, (T)b, (T)c, (T)d};
+    return __builtin_bit_cast(uint2, v);
+}
+
+// =====================================================================================================
+// Pointwise MFMA GEMM:  D[n][m] = sum_k W[n][k] * A[m][k]
+//   block = 256 threads = 4 waves; tile = 256 pixels x 32*CT couts; wave w owns pixels [64w, 64w+64) (2 MFMA
+//   pixel tiles) and all CT cout tiles.  K walked in 32-channel chunks: the A tile (256 px x 64 B) is staged
+//   global -> registers -> LDS (fp32 -> operand conversion and the optional per-channel SCA scale happen in that
+//   pass), the chunk's weight fragments (2*CT KiB, packed like the conv weights with one "tap") go through LDS too.
+// =====================================================================================================
+constexpr int PW_PX = 256;
+
+template <typename T, int CT, int MODE>
+__global__ __launch_bounds__(256, 2) void pointwise_mfma_kernel(const PointwiseParams p) {
+    __shared__ __attribute__((aligned(16))) uint4 lds_a[PW_PX * 4];
+    __shared__ __attribute__((aligned(16))) uint4 lds_w[2 * CT * 64];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int n_tiles = (p.N_tiles + CT - 1) / CT;  // blocks along couts
+    const int bm = blockIdx.x / n_tiles;
+    const int bn = blockIdx.x - bm * n_tiles;
+    const long m0 = (long)bm * PW_PX;
+
+    f32x16 acc[2][CT];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[pt][ct][i] = 0.f;
+
+    // staging plan: thread -> (pixel, 16-byte slot), 4 pieces per thread
+    const int chunks = p.K / 32;
+    for (int c = 0; c < chunks; ++c) {
+        uint4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int px = idx >> 2, s = idx & 3;
+            const long m = m0 + px;
+            v[i] = make_uint4(0, 0, 0, 0);
+            if (m < p.M) {
+                long row_off;
+                int kk = c * 32 + s * 8;
+                if (p.gather2x2) {
+                    // 2x2 stride-2 conv: k = (dy*2+dx)*Cin + ci ; output pixel m = (y, x) of the half-size grid
+                    const int Wo = p.Win >> 1;
+                    const int y = (int)(m / Wo), x = (int)(m - (long)y * Wo);
+                    const int sub = kk / p.Cin;
+                    kk -= sub * p.Cin;
+                    row_off = ((long)(2 * y + (sub >> 1)) * p.Win + (2 * x + (sub & 1))) * p.lda;
+                } else {
+                    row_off = m * p.lda;
+                }
+                float f[8];
+                if (p.a_f32) {
+                    const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.a) + row_off + kk);
+                    const f32x4 lo = src[0], hi = src[1];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f[j] = lo[j];
+                        f[4 + j] = hi[j];
+                    }
+                    if (p.a_scale) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) f[j] *= p.a_scale[kk + j];
+                    }
+                    v[i] = pack8f<T>(f);
+                } else {
+                    v[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.a) + row_off + kk);
+                    if (p.a_scale) {
+                        unpack8f<T>(v[i], f);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) f[j] *= p.a_scale[kk + j];
+                        v[i] = pack8f<T>(f);
+                    }
+                }
+            }
+        }
+        uint4 wv[(2 * CT * 64 + 255) / 256];
+#pragma unroll
+        for (int i = 0; i < (2 * CT * 64 + 255) / 256; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < 2 * CT * 64) {
+                // fragment order [chunk][ks][cout tile][lane]; this block's cout tiles start at bn*CT (MODE gate: see below)
+                const int ks = idx / (CT * 64), rem = idx - ks * (CT * 64);
+                const int ct = rem >> 6, ln = rem & 63;
+                int tile = bn * CT + ct;
+                if (MODE == PW_GATE) tile = bn * (CT / 2) + (ct >> 1) + (ct & 1) * (p.N_tiles / 2);  // pair n with n + N/2
+                wv[i] = tile < p.N_tiles
+                            ? reinterpret_cast<const uint4*>(p.wpk)[(((size_t)c * 2 + ks) * p.N_tiles + tile) * 64 + ln]
+                            : make_uint4(0, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int px = idx >> 2, s = idx & 3;
+            lds_a[px * 4 + (s ^ ((px >> 2) & 3))] = v[i];
+        }
+#pragma unroll
+        for (int i = 0; i < (2 * CT * 64 + 255) / 256; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < 2 * CT * 64) lds_w[idx] = wv[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 wf[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) wf[ct] = lds_w[(ks * CT + ct) * 64 + lane];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const int px = wave * 64 + pt * 32 + r;
+                const uint4 xf = lds_a[px * 4 + ((2 * ks + h) ^ ((px >> 2) & 3))];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = Tr<T>::mfma(wf[ct], xf, acc[pt][ct]);
+            }
+        }
+    }
+
+    // ---- epilogue: lane holds pixel (wave*64 + pt*32 + r), couts 32*tile + 8g + 4h + j ------------------------------
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+        const long m = m0 + wave * 64 + pt * 32 + r;
+        if (m >= p.M) continue;
+        if constexpr (MODE == PW_GATE) {
+            // SimpleGate fused: tiles (2q, 2q+1) hold channels n and n + N/2 of the same pixel -> out[n] = x1 * x2
+#pragma unroll
+            for (int q = 0; q < CT / 2; ++q) {
+                const int n_base = 32 * (bn * (CT / 2) + q);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n_base + 8 * g + 4 * h;
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        o[j] = (acc[pt][2 * q][4 * g + j] + p.bias[n + j]) *
+                               (acc[pt][2 * q + 1][4 * g + j] + p.bias[n + j + p.N_tiles * 16]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<T*>(p.out_typed) + m * p.ldo + n) =
+                        pack4f<T>(o[0], o[1], o[2], o[3]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int tile = bn * CT + ct;
+                if (tile >= p.N_tiles) continue;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = 32 * tile + 8 * g + 4 * h;
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = acc[pt][ct][4 * g + j] + (p.bias ? p.bias[n + j] : 0.f);
+                    if constexpr (MODE == PW_STORE) {
+                        if (p.out_typed)
+                            *reinterpret_cast<uint2*>(reinterpret_cast<T*>(p.out_typed) + m * p.ldo + n) =
+                                pack4f<T>(o[0], o[1], o[2], o[3]);
+                        if (p.out_f32) {
+                            f32x4 of = {o[0], o[1], o[2], o[3]};
+                            *reinterpret_cast<f32x4*>(p.out_f32 + m * p.ldf + n) = of;
+                        }
+                    } else if constexpr (MODE == PW_RESIDUAL) {
+                        // y = res + x * chan_scale   (beta / gamma residual of the NAFBlock)
+                        const f32x4 rs = *reinterpret_cast<const f32x4*>(p.res_f32 + m * p.ldf + n);
+                        f32x4 of;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) of[j] = rs[j] + o[j] * p.chan_scale[n + j];
+                        *reinterpret_cast<f32x4*>(p.out_f32 + m * p.ldf + n) = of;
+                    } else {  // PW_SHUFFLE_UP: n = (dy*2+dx)*Cup + co (weights permuted at pack time); m = (y, x) low-res
+                        const int Cup = p.N_tiles * 8;  // N / 4
+                        const int sub = n / Cup, co = n - sub * Cup;
+                        const int Wl = p.Win;
+                        const int y = (int)(m / Wl), x = (int)(m - (long)y * Wl);
+                        const long mo = (long)(2 * y + (sub >> 1)) * (2 * Wl) + (2 * x + (sub & 1));
+                        const f32x4 sk = *reinterpret_cast<const f32x4*>(p.res_f32 + mo * p.ldf + co);
+                        f32x4 of = {o[0] + sk[0], o[1] + sk[1], o[2] + sk[2], o[3] + sk[3]};
+                        *reinterpret_cast<f32x4*>(p.out_f32 + mo * p.ldf + co) = of;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+static void launch_pw_typed(const PointwiseParams& p, hipStream_t st) {
+    const long mb = (p.M + PW_PX - 1) / PW_PX;
+    dim3 block(256);
+#define FW_PW(CT, MODE)                                                                                         \
+    hipLaunchKernelGGL((pointwise_mfma_kernel<T, CT, MODE>), dim3((unsigned)(mb * ((p.N_tiles + CT - 1) / CT))), \
+                       block, 0, st, p)
+    switch (p.mode) {
+        case PW_STORE:
+            if (p.N_tiles >= 4) FW_PW(4, PW_STORE); else FW_PW(2, PW_STORE);
+            break;
+        case PW_RESIDUAL:
+            if (p.N_tiles >= 4) FW_PW(4, PW_RESIDUAL); else FW_PW(2, PW_RESIDUAL);
+            break;
+        case PW_SHUFFLE_UP:
+            if (p.N_tiles >= 4) FW_PW(4, PW_SHUFFLE_UP); else FW_PW(2, PW_SHUFFLE_UP);
+            break;
+        case PW_GATE:
+            // CT cout tiles per block = CT/2 gated tiles; N_tiles is the un-gated count (even)
+            if (p.N_tiles >= 8) {
+                hipLaunchKernelGGL((pointwise_mfma_kernel<T, 4, PW_GATE>), dim3((unsigned)(mb * (p.N_tiles / 4))), block, 0,
+                                   st, p);
+            } else {
+                hipLaunchKernelGGL((pointwise_mfma_kernel<T, 2, PW_GATE>), dim3((unsigned)(mb * (p.N_tiles / 2))), block, 0,
+                                   st, p);
+            }
+            break;
+        default:
+            throw Error(1, "pointwise: bad mode");
+    }
+#undef FW_PW
+    FW_HIP_CHECK(hipGetLastError());
+}
+
+void launch_pointwise(DType dt, const PointwiseParams& p, hipStream_t st) {
+    if (p.M <= 0 || p.K <= 0 || (p.K & 31) || p.N_tiles <= 0) throw Error(1, "pointwise: bad shape");
+    if (p.mode == PW_GATE && (p.N_tiles & 1)) throw Error(1, "pointwise: gate needs an even number of cout tiles");
+    if (p.gather2x2 && (p.Cin & 31)) throw Error(1, "pointwise: 2x2 gather needs Cin % 32 == 0");
+    if (dt == DT_BF16)
+        launch_pw_typed<__bf16>(p, st);
+    else
+        launch_pw_typed<_Float16>(p, st);
+}
+
+// Host-side packer for pointwise weights: w[cout][K] fp32 (already in the kernel's k order) ->
+// fragments [chunk][ks][cout tile][lane][8]; returns uint16 count.
+size_t pack_pointwise_weights(DType dt, const float* w, int cout, int K, uint16_t* dst) {
+    const int nt = (cout + 31) / 32, chunks = (K + 31) / 32;
+    const size_t n = (size_t)chunks * 2 * nt * 64 * 8;
+    if (!dst) return n;
+    size_t o = 0;
+    for (int c = 0; c < chunks; ++c)
+        for (int ks = 0; ks < 2; ++ks)
+            for (int t = 0; t < nt; ++t)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = 32 * t + (lane & 31);
+                        const int k = 32 * c + 16 * ks + 8 * (lane >> 5) + j;
+                        dst[o++] = f32_to_operand(dt, (co < cout && k < K) ? w[(size_t)co * K + k] : 0.f);
+                    }
+    return n;
+}
+
+// =====================================================================================================
+// LayerNorm2d over channels, fp32 in -> operand-typed out.  One wave per pixel; lane l holds channels
+// 4l..4l+3 (+256 per extra pass).  eps = 1e-6.
+// =====================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm2d_kernel(const float* __restrict__ x, long M, int C, const float* w,
+                                                          const float* b, T* out, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long m = wave0; m < M; m += nwaves) {
+        const float* row = x + m * C;
+        float v[16];  // up to C = 1024
+        float s = 0.f;
+        const int passes = (C + 255) / 256;
+#pragma unroll
+        for (int pss = 0; pss < 4; ++pss) {
+            if (pss < passes) {
+                const int c0 = pss * 256 + lane * 4;
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                if (c0 < C) t = *reinterpret_cast<const f32x4*>(row + c0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[pss * 4 + j] = t[j];
+                    s += t[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / C;
+        float q = 0.f;
+#pragma unroll
+        for (int pss = 0; pss < 4; ++pss) {
+            if (pss < passes) {
+                const int c0 = pss * 256 + lane * 4;
+                if (c0 < C) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float d = v[pss * 4 + j] - mean;
+                        q += d * d;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = 1.0f / sqrtf(q / C + eps);
+#pragma unroll
+        for (int pss = 0; pss < 4; ++pss) {
+            if (pss < passes) {
+                const int c0 = pss * 256 + lane * 4;
+                if (c0 < C) {
+                    float o4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o4[j] = (v[pss * 4 + j] - mean) * rstd * w[c0 + j] + b[c0 + j];
+                    *reinterpret_cast<uint2*>(out + m * C + c0) = pack4f<T>(o4[0], o4[1], o4[2], o4[3]);
+                }
+            }
+        }
+    }
+}
+
+void launch_layernorm2d(DType dt, const float* x, long M, int C, const float* w, const float* b, void* out,
+                        hipStream_t st) {
+    if (C < 4 || (C & 3) || C > 1024) throw Error(1, "layernorm2d: C must be a multiple of 4, <= 1024");
+    const long blocks = (M + 3) / 4 < 4096 ? (M + 3) / 4 : 4096;
+    if (dt == DT_BF16)
+        hipLaunchKernelGGL((layernorm2d_kernel<__bf16>), dim3((unsigned)blocks), dim3(256), 0, st, x, M, C, w, b,
+                           (__bf16*)out, 1e-6f);
+    else
+        hipLaunchKernelGGL((layernorm2d_kernel<_Float16>), dim3((unsigned)blocks), dim3(256), 0, st, x, M, C, w, b,
+                           (_Float16*)out, 1e-6f);
+    FW_HIP_CHECK(hipGetLastError());
+}
+
+// =====================================================================================================
+// Depthwise 3x3 (zero pad 1) on a 2C-channel operand-typed NHWC tensor, fused SimpleGate (out[c] = dw[c] * dw[c+C]) and
+// per-channel partial sums of the gated output (for the SCA global average pool).  One thread = one pixel x 8
+// gated channels.
+// =====================================================================================================
+constexpr int DW_MAX_BLOCKS = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_gate_kernel(const T* __restrict__ x, int H, int W, int C, const float* wdw,
+                                                             const float* bdw, T* out, float* partial) {
+    // wdw: [2C][9] fp32, bdw: [2C].  groups = C/8 divides 256 (C is a power-of-two multiple of 32 here), so a thread keeps
+    // the same channel group for its whole grid-stride loop and the SCA pooling is a fixed-order (deterministic) reduction:
+    // registers -> LDS -> partial[block][C] -> sca_kernel.
+    __shared__ float red[256][8];
+    const int groups = C / 8;
+    const long total = (long)H * W * groups;
+    const int g = threadIdx.x % groups;
+    float cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float wr[2][8][9];
+    float br[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        br[0][j] = bdw[g * 8 + j];
+        br[1][j] = bdw[C + g * 8 + j];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            wr[0][j][t] = wdw[(g * 8 + j) * 9 + t];
+            wr[1][j][t] = wdw[(C + g * 8 + j) * 9 + t];
+        }
+    }
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long pix = idx / groups;
+        const int yy = (int)(pix / W), xx = (int)(pix - (long)yy * W);
+        float a1[8], a2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            a1[j] = br[0][j];
+            a2[j] = br[1][j];
+        }
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int sy = yy + dy;
+            if (sy < 0 || sy >= H) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int sx = xx + dx;
+                if (sx < 0 || sx >= W) continue;
+                const T* src = x + ((long)sy * W + sx) * (2 * C);
+                float f1[8], f2[8];
+                unpack8f<T>(*reinterpret_cast<const uint4*>(src + g * 8), f1);
+                unpack8f<T>(*reinterpret_cast<const uint4*>(src + C + g * 8), f2);
+                const int tap = (dy + 1) * 3 + (dx + 1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    a1[j] += f1[j] * wr[0][j][tap];
+                    a2[j] += f2[j] * wr[1][j][tap];
+                }
+            }
+        }
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            o[j] = a1[j] * a2[j];
+            cs[j] += o[j];
+        }
+        *reinterpret_cast<uint4*>(out + pix * C + g * 8) = pack8f<T>(o);
+    }
+    if (partial) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = cs[j];
+        __syncthreads();
+        if (threadIdx.x < C) {
+            const int gg = threadIdx.x / 8, j = threadIdx.x % 8;
+            float s = 0.f;
+            for (int t = gg; t < 256; t += groups) s += red[t][j];
+            partial[(long)blockIdx.x * C + threadIdx.x] = s;
+        }
+        if (C > 256) {
+            for (int c = 256 + threadIdx.x; c < C; c += 256) {
+                const int gg = c / 8, j = c % 8;
+                float s = 0.f;
+                for (int t = gg; t < 256; t += groups) s += red[t][j];
+                partial[(long)blockIdx.x * C + c] = s;
+            }
+        }
+    }
+}
+
+int dwconv_blocks(int H, int W, int C) {
+    const long total = (long)H * W * (C / 8);
+    const long b = (total + 255) / 256;
+    return (int)(b < DW_MAX_BLOCKS ? b : DW_MAX_BLOCKS);
+}
+
+void launch_dwconv3x3_gate(DType dt, const void* x, int H, int W, int C, const float* wdw, const float* bdw, void* out,
+                           float* partial, hipStream_t st) {
+    if (C < 32 || (C & (C - 1)) || C > 1024) throw Error(1, "dwconv3x3_gate: C must be a power of two in [32, 1024]");
+    const int blocks = dwconv_blocks(H, W, C);
+    if (dt == DT_BF16)
+        hipLaunchKernelGGL((dwconv3x3_gate_kernel<__bf16>), dim3((unsigned)blocks), dim3(256), 0, st, (const __bf16*)x, H,
+                           W, C, wdw, bdw, (__bf16*)out, partial);
+    else
+        hipLaunchKernelGGL((dwconv3x3_gate_kernel<_Float16>), dim3((unsigned)blocks), dim3(256), 0, st,
+                           (const _Float16*)x, H, W, C, wdw, bdw, (_Float16*)out, partial);
+    FW_HIP_CHECK(hipGetLastError());
+}
+
+// SCA: s[n] = b[n] + sum_k W[n][k] * mean[k], mean[k] = (sum over blocks of partial[b][k]) / HW, summed in block order
+// (deterministic).  One wave per output channel.
+__global__ __launch_bounds__(256) void sca_kernel(const float* __restrict__ partial, int nblocks, float inv_hw, int C,
+                                                  const float* w, const float* b, float* s) {
+    const int lane = threadIdx.x & 63;
+    const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (n >= C) return;
+    float a = 0.f;
+    for (int k = lane; k < C; k += 64) {
+        float m = 0.f;
+        for (int q = 0; q < nblocks; ++q) m += partial[(long)q * C + k];
+        a += w[(long)n * C + k] * (m * inv_hw);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) s[n] = a + b[n];
+}
+
+void launch_sca(const float* partial, int nblocks, long HW, int C, const float* w, const float* b, float* s,
+                hipStream_t st) {
+    hipLaunchKernelGGL(sca_kernel, dim3((C * 64 + 255) / 256), dim3(256), 0, st, partial, nblocks, 1.0f / (float)HW, C, w, b,
+                       s);
+    FW_HIP_CHECK(hipGetLastError());
+}
+
+// fp32 NHWC [M][C] -> operand-typed chunk-planar [C/32][M][32] (input layout of conv3x3_mfma's trunk form)
+template <typename T>
+__global__ __launch_bounds__(256) void f32_to_planar_kernel(const float* __restrict__ x, long M, int C, T* out) {
+    const int groups = C / 8;
+    const long total = M * groups;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / groups;
+        const int g = (int)(i - m * groups);
+        const f32x4* src = reinterpret_cast<const f32x4*>(x + m * C + g * 8);
+        const f32x4 lo = src[0], hi = src[1];
+        float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const int plane = g >> 2, s = g & 3;
+        *reinterpret_cast<uint4*>(out + ((size_t)plane * M + m) * 32 + s * 8) = pack8f<T>(f);
+    }
+}
+
+void launch_f32_to_planar(DType dt, const float* x, long M, int C, void* out, hipStream_t st) {
+    if (C & 31) throw Error(1, "f32_to_planar: C must be a multiple of 32");
+    const long total = M * (C / 8);
+    const long blocks = (total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096;
+    if (dt == DT_BF16)
+        hipLaunchKernelGGL((f32_to_planar_kernel<__bf16>), dim3((unsigned)blocks), dim3(256), 0, st, x, M, C, (__bf16*)out);
+    else
+        hipLaunchKernelGGL((f32_to_planar_kernel<_Float16>), dim3((unsigned)blocks), dim3(256), 0, st, x, M, C,
+                           (_Float16*)out);
+    FW_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace fw

@@ -33,6 +33,13 @@ struct Workspace {
 
 using namespace fw;
 
+namespace fw {
+std::string& last_error_ref() {
+    thread_local std::string msg;
+    return msg;
+}
+}  // namespace fw
+
 struct fw_rrdbnet {
     int device = 0;
     int num_block = 0;
@@ -52,10 +59,8 @@ struct fw_rrdbnet {
 
 namespace {
 
-thread_local std::string g_last_error;
-
 int fail(int code, const std::string& msg) {
-    g_last_error = msg;
+    fw::last_error_ref() = msg;
     return code;
 }
 
@@ -319,7 +324,7 @@ void forward(fw_rrdbnet* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, f
 
 extern "C" {
 
-const char* fw_last_error(void) { return g_last_error.c_str(); }
+const char* fw_last_error(void) { return fw::last_error_ref().c_str(); }
 
 int fw_abi_version(void) { return 1; }
 

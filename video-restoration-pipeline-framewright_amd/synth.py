@@ -95,3 +95,62 @@ def synthetic_clip(num_frames: int, height: int, width: int, seed: int) -> Itera
 
 def synthetic_frames(num_frames: int, height: int, width: int, seed: int) -> np.ndarray:
     return np.stack(list(synthetic_clip(num_frames, height, width, seed)))
+
+
+def nafnet_tensor_shapes(width: int, middle_blk_num: int, enc_blk_nums, dec_blk_nums) -> List[Tuple[str, Tuple[int, ...]]]:
+    """[(key, shape)] of the NAFNet state-dict (module tree of SURVEY.md §A.3; reference constructor arguments at
+    src/framewright/processors/tap_denoise.py:340-346)."""
+    out: List[Tuple[str, Tuple[int, ...]]] = [("intro.weight", (width, 3, 3, 3)), ("intro.bias", (width,)),
+                                              ("ending.weight", (3, width, 3, 3)), ("ending.bias", (3,))]
+
+    def block(prefix: str, c: int):
+        return [(prefix + "conv1.weight", (2 * c, c, 1, 1)), (prefix + "conv1.bias", (2 * c,)),
+                (prefix + "conv2.weight", (2 * c, 1, 3, 3)), (prefix + "conv2.bias", (2 * c,)),
+                (prefix + "conv3.weight", (c, c, 1, 1)), (prefix + "conv3.bias", (c,)),
+                (prefix + "sca.1.weight", (c, c, 1, 1)), (prefix + "sca.1.bias", (c,)),
+                (prefix + "conv4.weight", (2 * c, c, 1, 1)), (prefix + "conv4.bias", (2 * c,)),
+                (prefix + "conv5.weight", (c, c, 1, 1)), (prefix + "conv5.bias", (c,)),
+                (prefix + "norm1.weight", (c,)), (prefix + "norm1.bias", (c,)),
+                (prefix + "norm2.weight", (c,)), (prefix + "norm2.bias", (c,)),
+                (prefix + "beta", (1, c, 1, 1)), (prefix + "gamma", (1, c, 1, 1))]
+
+    c = width
+    for l, nb in enumerate(enc_blk_nums):
+        for j in range(nb):
+            out += block(f"encoders.{l}.{j}.", c)
+        out += [(f"downs.{l}.weight", (2 * c, c, 2, 2)), (f"downs.{l}.bias", (2 * c,))]
+        c *= 2
+    for j in range(middle_blk_num):
+        out += block(f"middle_blks.{j}.", c)
+    for i, nb in enumerate(dec_blk_nums):
+        out += [(f"ups.{i}.0.weight", (2 * c, c, 1, 1))]
+        c //= 2
+        for j in range(nb):
+            out += block(f"decoders.{i}.{j}.", c)
+    return out
+
+
+def synthetic_nafnet_state(width: int = 64, middle_blk_num: int = 12, enc_blk_nums=(2, 2, 4, 8),
+                           dec_blk_nums=(2, 2, 2, 2), seed: int = 4321) -> Dict[str, np.ndarray]:
+    """Seeded NAFNet weights: PyTorch default conv init restated (U(+-1/sqrt(fan_in))), LayerNorm weight 1 +- 0.1 /
+    bias +-0.1, beta/gamma U(-0.3, 0.3) (upstream initialises them to 0, which would make every block the identity),
+    ending scaled by 0.1 so that the output stays an image-like perturbation of the input."""
+    rng = np.random.default_rng(seed)
+    sd: Dict[str, np.ndarray] = {}
+    for key, shape in nafnet_tensor_shapes(width, middle_blk_num, enc_blk_nums, dec_blk_nums):
+        if key.endswith("beta") or key.endswith("gamma"):
+            v = rng.uniform(-0.3, 0.3, size=shape)
+        elif ".norm" in key:
+            v = (1.0 + rng.uniform(-0.1, 0.1, size=shape)) if key.endswith("weight") else rng.uniform(-0.1, 0.1, size=shape)
+        else:
+            if key.endswith("weight"):
+                fan_in = int(np.prod(shape[1:]))
+            else:
+                wshape = dict(nafnet_tensor_shapes(width, middle_blk_num, enc_blk_nums, dec_blk_nums))[key[:-4] + "weight"]
+                fan_in = int(np.prod(wshape[1:]))
+            bound = 1.0 / np.sqrt(fan_in)
+            v = rng.uniform(-bound, bound, size=shape)
+            if key.startswith("ending."):
+                v = v * 0.1
+        sd[key] = v.astype(np.float32)
+    return sd
