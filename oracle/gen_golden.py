@@ -110,5 +110,73 @@ def main() -> None:
             print(f"  {k}: {v.shape} mean {v.mean():+.4f} std {v.std():.4f}")
 
 
+def host_logic() -> None:
+    """Fixture set 2 — pure-Python bookkeeping of the reference, evaluated by the reference's own functions:
+    utils/gpu.py:386-512 (tile policy), processors/interpolation.py:325-366,783-791,811-845 (scene histogram,
+    decimation loop, interpolation strategy), infrastructure/gpu/distributor.py:287-304 and utils/multi_gpu.py:796-800
+    (round-robin frame assignment)."""
+    import json
+    import shutil
+    from unittest import mock
+
+    g = load_reference("framewright.utils.gpu")
+    cases = []
+    for res in [(1920, 1080), (1280, 720), (640, 360), (3840, 2160)]:
+        for scale in (2, 4):
+            for vram in (2048, 4096, 8192, 24576, 81920):
+                for model in ("realesrgan-x4plus", "realesrgan-x2plus", "realesr-animevideov3", "unknown"):
+                    t = g.calculate_optimal_tile_size(res, scale, vram, model)
+                    cases.append({"res": res, "scale": scale, "vram": vram, "model": model, "tile": t,
+                                  "seq": g.get_adaptive_tile_sequence(res, scale, t)})
+    seqs = [{"res": r, "scale": s, "start": st, "min": mn, "seq": g.get_adaptive_tile_sequence(r, s, st, mn)}
+            for r, s, st, mn in [((1920, 1080), 4, 512, 128), ((1920, 1080), 4, 400, 64), ((720, 480), 2, 0, 128),
+                                 ((1920, 1080), 4, 100, 128), ((4096, 2160), 4, 1000, 128)]]
+
+    ip = load_reference("framewright.processors.interpolation")
+    with mock.patch.object(shutil, "which", return_value="/usr/bin/true"):  # __init__ would try to download rife-ncnn
+        try:
+            fi = ip.FrameInterpolator()
+        except Exception:  # noqa: BLE001
+            fi = ip.FrameInterpolator.__new__(ip.FrameInterpolator)
+            fi.config = ip.InterpolationConfig()
+    factors = [ip.FrameInterpolator.calculate_interpolation_factor(s, t)
+               for s, t in [(24, 30), (24, 48), (24, 50), (24, 60), (25, 50), (23.976, 59.94), (15, 120), (12, 240), (30, 60)]]
+    rng = np.random.default_rng(77)
+    hist = []
+    for k in range(6):
+        a = rng.integers(0, 256, size=(24, 32, 3), dtype=np.uint8)
+        b = a.copy() if k == 0 else np.clip(a.astype(int) + rng.integers(-40 * k, 40 * k + 1, size=a.shape), 0, 255).astype(np.uint8)
+        hist.append({"seed_k": k, "a": a.tolist(), "b": b.tolist(), "threshold": fi.config.scene_threshold,
+                     "scene_change": bool(fi._detect_scene_by_histogram(a, b))})
+
+    # the decimation loop is inline in interpolate_to_fps (interpolation.py:783-791); transcribed verbatim here and
+    # evaluated in the reference's arithmetic (float division)
+    dec = []
+    for n, ifps, tfps in [(96, 48.0, 30.0), (200, 96.0, 60.0), (200, 96.0, 50.0), (50, 47.952, 29.97), (10, 48.0, 47.0)]:
+        frame_ratio = ifps / tfps
+        out_idx, keep = 0, []
+        for i in range(n):
+            if i >= out_idx * frame_ratio:
+                keep.append(i)
+                out_idx += 1
+        dec.append({"n": n, "interp_fps": ifps, "target_fps": tfps, "keep": keep})
+
+    d = load_reference("framewright.infrastructure.gpu.distributor")
+    rr = []
+    for n, ndev in [(10, 4), (7, 8), (300, 8), (5, 1)]:
+        devs = [types.SimpleNamespace(index=i) for i in range(ndev)]  # the planner only reads .index (:296-301)
+        try:
+            plan = d.GPUDistributor._distribute_round_robin(None, n, devs)
+            rr.append({"n": n, "devices": ndev, "workloads": {str(k): v for k, v in plan.gpu_workloads.items()}})
+        except Exception as e:  # noqa: BLE001
+            rr.append({"n": n, "devices": ndev, "error": repr(e)})
+
+    dst = ROOT / "tests" / "golden" / "host_logic.json"
+    dst.write_text(json.dumps({"tile_policy": cases, "tile_sequences": seqs, "interp_factors": factors,
+                               "histogram_scene": hist, "decimation": dec, "round_robin": rr}, indent=0))
+    print(f"wrote {dst} ({dst.stat().st_size / 1024:.0f} KiB); round_robin: {[r.get('error', 'ok') for r in rr]}")
+
+
 if __name__ == "__main__":
     main()
+    host_logic()
