@@ -131,6 +131,16 @@ int fw_conv3x3_nhwc(int dtype, const void* x, int in_cstride, long in_plane_stri
                     int upsample2x, const float* res1, float s1, const float* res2, float s2, void* out,
                     int out_cstride, long out_plane_stride, int out_coff, float* out_f32, void* stream);
 
+/* Same, with the extras the IFNet blocks need: chan_scale (fp32 [32*cout_tiles] or NULL) multiplies (acc + bias) per
+ * output channel before the residual add, post_act = 1 applies LeakyReLU(0.2) AFTER the residual add
+ * (ResConv: lrelu(conv(x) * beta + x)), and f32_cstride / f32_coff place res1 / res2 / out_f32 in a
+ * channel slice of a wider fp32 NHWC buffer (0 / 0 = a dense 32*cout_tiles-channel buffer). */
+int fw_conv3x3_nhwc_ex(int dtype, const void* x, int in_cstride, long in_plane_stride, int cin_chunks, int height,
+                       int width, const void* packed_weight, const float* bias, int cout_tiles, int act_lrelu,
+                       int upsample2x, const float* res1, float s1, const float* res2, float s2, const float* chan_scale,
+                       int post_act, int f32_cstride, int f32_coff, void* out, int out_cstride, long out_plane_stride,
+                       int out_coff, float* out_f32, void* stream);
+
 /* -------------------------------------------------------------------------------------------------
  * TAP temporal denoise: NAFNet
  * replaces  basicsr NAFNet construction + load in TAPDenoiser._load_nafnet (processors/tap_denoise.py:335-364),
@@ -180,6 +190,46 @@ int fw_temporal_average_u8(const uint8_t* const* frames, const float* weights, i
  * reference's Python float: (1 - s) is formed in double, then both factors are rounded once to float32. */
 int fw_strength_blend_u8(const uint8_t* original, const uint8_t* denoised, double strength, size_t nbytes, uint8_t* out,
                          void* stream);
+
+/* -------------------------------------------------------------------------------------------------
+ * RIFE frame interpolation: IFNet v4.6 building blocks (device pointers, fp32 NHWC small-channel tensors)
+ * replaces  the arithmetic inside the external binary the reference shells out to,
+ *           `rife-ncnn-vulkan -m rife-v4.6` (processors/interpolation.py:628-650); architecture per SURVEY.md §A.5.
+ *           The convolutions of the IFBlocks run through fw_conv3x3_nhwc_ex; the host sequencing is
+ *           framewright_amd/rife.py (IFNetEngine).
+ * ------------------------------------------------------------------------------------------------- */
+
+/* uint8 BGR H x W x 3 -> fp32 RGB/255 [padded_h][padded_w][3], zero outside H x W. */
+int fw_u8_to_rgb_f32(const uint8_t* in_bgr, int height, int width, int padded_height, int padded_width, float* out,
+                     void* stream);
+
+/* dst[y][x][dst_coff + c] = mul * F.interpolate(src, scale_factor, "bilinear", align_corners=False)[c][y][x]. */
+int fw_resize_bilinear_f32(const float* src, int src_h, int src_w, int channels, float* dst, int dst_h, int dst_w,
+                           int dst_cstride, int dst_coff, float scale_factor, float mul, void* stream);
+
+/* x = cat(warp(img0, flow[:2]), warp(img1, flow[2:4]), timestep, mask) (8 ch) — or cat(img0, img1, timestep) (7 ch) when
+ * flow == mask == NULL.  warp = grid_sample(bilinear, border, align_corners=True) with the flow in pixels. */
+int fw_ifnet_build_x(const float* img0, const float* img1, const float* flow, const float* mask, int height, int width,
+                     float timestep, float* x, void* stream);
+
+/* pixel_unshuffle(2) + cast: src [h][w][src_cstride] (fp32 if src_is_f32, else operand-typed; first `channels` used) ->
+ * dst operand-typed [h/2][w/2][dst_channels], channel c*4 + dy*2 + dx, zero above 4*channels.  Front end of the
+ * stride-2 convolutions, which run as 3x3 convolutions on the unshuffled tensor. */
+int fw_unshuffle2_cast(int dtype, const void* src, int src_is_f32, int height, int width, int channels, int src_cstride,
+                       void* dst, int dst_channels, void* stream);
+
+/* [h][w][>=96] with channel ((c6*4 + qy*2 + qx)*4 + py*2 + px) -> [4h][4w][6]: ConvTranspose2d(4,2,1) evaluated as a
+ * 3x3 conv with 4 output parities, followed by PixelShuffle(2). */
+int fw_depth_to_space4_f32(const float* src, int height, int width, int src_cstride, float* dst, void* stream);
+
+/* flow (+)= bilinear_up(tmp)[:4] * scale ; mask (+)= bilinear_up(tmp)[4]   (first != 0: assign). */
+int fw_ifnet_accumulate(const float* tmp, int tmp_h, int tmp_w, int height, int width, float scale, float* flow, float* mask,
+                        int first, void* stream);
+
+/* merged = warp(img0, flow[:2]) * sigmoid(mask) + warp(img1, flow[2:4]) * (1 - sigmoid(mask)), cropped to H x W;
+ * out_bgr = round_half_even(clamp(merged, 0, 1) * 255) (BGR), out_rgb_f32 = merged (RGB); either may be NULL. */
+int fw_ifnet_blend(const float* img0, const float* img1, const float* flow, const float* mask, int padded_height,
+                   int padded_width, int height, int width, uint8_t* out_bgr, float* out_rgb_f32, void* stream);
 
 #ifdef __cplusplus
 }

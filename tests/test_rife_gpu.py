@@ -1,0 +1,135 @@
+"""RIFE / IFNet v4.6 on the GPU: the HBM-bound kernels against torch (F.interpolate, F.grid_sample, pixel shuffle),
+the two weight transforms (stride-2 conv and ConvTranspose2d as 3x3 convs) against torch convs, and the whole network
+against the fp32 CPU oracle (oracle/ifnet_ref.py; parity vs upstream rife-ncnn-vulkan is unpinned).
+Tolerance for the network: max-abs < 4e-3 on the [0,1] float frame and <= 2 LSB on uint8 with f16 operands (flow errors
+are amplified by image gradients in the warp), PSNR >= 50 dB."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from framewright_amd import _lib
+from framewright_amd import rife as RF
+from framewright_amd.synth import synthetic_frames, synthetic_ifnet_state
+from oracle import ifnet_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+@pytest.mark.parametrize("sf", [0.125, 0.25, 0.5, 1.0, 2.0, 4.0, 8.0])
+def test_resize_bilinear_matches_torch(hip_lib, sf):
+    torch.manual_seed(int(sf * 100))
+    hs, ws = (64, 96) if sf < 1 else (16, 24)
+    src = torch.rand(hs, ws, 5, device="cuda")
+    hd, wd = int(hs * sf), int(ws * sf)
+    dst = torch.zeros(hd, wd, 7, device="cuda")
+    _lib.check(hip_lib.fw_resize_bilinear_f32(_p(src), hs, ws, 5, _p(dst), hd, wd, 7, 2, sf, 0.5, None))
+    torch.cuda.synchronize()
+    want = F.interpolate(src.permute(2, 0, 1).unsqueeze(0), scale_factor=sf, mode="bilinear", align_corners=False)[0]
+    assert (dst[..., 2:] - 0.5 * want.permute(1, 2, 0)).abs().max().item() < 1e-5
+    assert (dst[..., :2] == 0).all()
+
+
+def test_warp_and_build_x_match_grid_sample(hip_lib):
+    torch.manual_seed(3)
+    H, W = 40, 56
+    i0, i1 = torch.rand(H, W, 3, device="cuda"), torch.rand(H, W, 3, device="cuda")
+    flow = (torch.rand(H, W, 4, device="cuda") - 0.5) * 12      # up to +-6 px, leaves the image at the borders
+    mask = torch.randn(H, W, 1, device="cuda")
+    X = torch.zeros(H, W, 8, device="cuda")
+    _lib.check(hip_lib.fw_ifnet_build_x(_p(i0), _p(i1), _p(flow), _p(mask), H, W, 0.5, _p(X), None))
+    torch.cuda.synchronize()
+    n = lambda t: t.permute(2, 0, 1).unsqueeze(0).cpu()
+    w0 = ifnet_ref.warp(n(i0), n(flow)[:, :2])[0].permute(1, 2, 0)
+    w1 = ifnet_ref.warp(n(i1), n(flow)[:, 2:4])[0].permute(1, 2, 0)
+    assert (X[..., :3].cpu() - w0).abs().max().item() < 2e-5
+    assert (X[..., 3:6].cpu() - w1).abs().max().item() < 2e-5
+    assert (X[..., 6] == 0.5).all() and torch.equal(X[..., 7], mask[..., 0])
+    X7 = torch.zeros(H, W, 7, device="cuda")
+    _lib.check(hip_lib.fw_ifnet_build_x(_p(i0), _p(i1), None, None, H, W, 0.5, _p(X7), None))
+    torch.cuda.synchronize()
+    assert torch.equal(X7[..., :3], i0) and torch.equal(X7[..., 3:6], i1)
+
+
+def test_stride2_and_transposed_conv_as_3x3(hip_lib):
+    """The two weight transforms of rife.py, evaluated with torch convs on the CPU (pure algebra)."""
+    torch.manual_seed(5)
+    x = torch.randn(1, 6, 16, 20)
+    w, b = torch.randn(10, 6, 3, 3), torch.randn(10)
+    want = F.conv2d(x, w, b, stride=2, padding=1)
+    got = F.conv2d(F.pixel_unshuffle(x, 2), torch.from_numpy(RF.stride2_as_unshuffled_3x3(w.numpy())), b, padding=1)
+    assert (got - want).abs().max().item() < 1e-5
+    wt, bt = torch.randn(6, 24, 4, 4), torch.randn(24)
+    want = F.pixel_shuffle(F.conv_transpose2d(x, wt, bt, stride=2, padding=1), 2)
+    w3, b3 = RF.convtranspose_as_3x3(wt.numpy(), bt.numpy())
+    y = F.conv2d(x, torch.from_numpy(w3), torch.from_numpy(b3), padding=1)          # [1][96][h][w]
+    src = y[0].permute(1, 2, 0).contiguous().cuda()
+    dst = torch.zeros(4 * 16, 4 * 20, 6, device="cuda")
+    _lib.check(hip_lib.fw_depth_to_space4_f32(_p(src), 16, 20, 96, _p(dst), None))
+    torch.cuda.synchronize()
+    assert (dst.cpu().permute(2, 0, 1) - want[0]).abs().max().item() < 1e-5
+
+
+def test_unshuffle_cast(hip_lib):
+    x = torch.randn(12, 20, 7, device="cuda")
+    dst = torch.full((6, 10, 32), 9.0, dtype=torch.float16, device="cuda")
+    _lib.check(hip_lib.fw_unshuffle2_cast(_lib.FW_DTYPE_F16, _p(x), 1, 12, 20, 7, 7, _p(dst), 32, None))
+    torch.cuda.synchronize()
+    want = F.pixel_unshuffle(x.permute(2, 0, 1).unsqueeze(0), 2)[0].permute(1, 2, 0)
+    assert torch.equal(dst[..., :28], want.half()) and (dst[..., 28:] == 0).all()
+
+
+@pytest.mark.parametrize("dtype,tol,lsb", [("f16", 4e-3, 2), ("bf16", 3e-2, 8)])
+@pytest.mark.parametrize("H,W,gain", [(64, 96, 1.0), (70, 100, 1.0), (96, 128, 12.0)])
+def test_ifnet_vs_oracle(hip_lib, dtype, tol, lsb, H, W, gain):
+    sd = synthetic_ifnet_state(seed=2468, flow_gain=gain)
+    eng = RF.IFNetEngine(dtype)
+    eng.load_state_dict(sd)
+    fr = synthetic_frames(2, H, W, seed=H)
+    a, b = torch.from_numpy(fr[0]).cuda(), torch.from_numpy(fr[1]).cuda()
+    rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    u8 = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+    eng.interpolate_device(a, b, 0.5, out=u8, out_rgb_f32=rgb)
+    torch.cuda.synchronize()
+    t = lambda f: torch.from_numpy(f[:, :, ::-1].astype(np.float32) / 255.0).permute(2, 0, 1).unsqueeze(0)
+    with torch.no_grad():
+        want = ifnet_ref.ifnet_forward({k: torch.from_numpy(v) for k, v in sd.items()}, t(fr[0]), t(fr[1]), 0.5)
+    want = want[0].permute(1, 2, 0).numpy()
+    err = np.abs(rgb.cpu().numpy() - want).max()
+    want_u8 = (np.clip(want, 0, 1) * 255.0).round().astype(np.uint8)[:, :, ::-1]
+    d = np.abs(u8.cpu().numpy().astype(int) - want_u8.astype(int))
+    mse = np.mean(d.astype(np.float64) ** 2)
+    psnr = 99.0 if mse == 0 else 10 * math.log10(255.0 ** 2 / mse)
+    flow = eng._last_flow.abs().mean().item()
+    print(f"{dtype} {H}x{W}: max-abs {err:.2e}, uint8 max diff {d.max()}, PSNR {psnr:.1f} dB, mean |flow| {flow:.2f} px, "
+          f"|out - avg| {np.abs(want - (fr[0][:, :, ::-1] / 255.0 + fr[1][:, :, ::-1] / 255.0) / 2).mean():.4f}")
+    assert err < tol and d.max() <= lsb and psnr >= 50.0
+    assert np.array_equal(eng.interpolate(fr[0], fr[1]), u8.cpu().numpy())
+
+
+def test_frame_interpolator_directory_contract(hip_lib, tmp_path, monkeypatch):
+    from PIL import Image
+    monkeypatch.setenv("FRAMEWRIGHT_AMD_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("FRAMEWRIGHT_MODEL_DIR", str(tmp_path / "none"))
+    src = tmp_path / "in"
+    src.mkdir()
+    frames = synthetic_frames(4, 40, 64, seed=12)
+    for i, f in enumerate(frames):
+        Image.fromarray(f[:, :, ::-1]).save(src / f"frame_{i + 1:08d}.png")
+    fi = RF.FrameInterpolator()
+    out = fi.interpolate(src, tmp_path / "x2", 24, 48)
+    assert len(list(out.glob("frame_*.png"))) == 7
+    assert np.array_equal(np.asarray(Image.open(out / "frame_00000001.png"))[:, :, ::-1], frames[0])
+    out2, fps = fi.interpolate_to_fps(src, tmp_path / "to30", 24, 30)
+    assert fps == 30 and len(list(out2.glob("*.png"))) == len(RF.policy.decimation_indices(7, 48, 30))
+    out3, fps3 = fi.interpolate_to_fps(src, tmp_path / "copy", 24, 24)
+    assert fps3 == 24 and len(list(out3.glob("*.png"))) == 4
+    with pytest.raises(RF.InterpolationError):
+        fi.interpolate(tmp_path / "empty_does_not_exist", tmp_path / "o", 24, 48)

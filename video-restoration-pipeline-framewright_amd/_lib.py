@@ -28,6 +28,8 @@ EXPORTS = [
     "fw_nafnet_create", "fw_nafnet_set_tensor", "fw_nafnet_finalize", "fw_nafnet_denoise_u8", "fw_nafnet_flops",
     "fw_nafnet_destroy", "fw_u8_crop", "fw_tile_blend_accumulate", "fw_tile_blend_finish", "fw_temporal_average_u8",
     "fw_strength_blend_u8",
+    "fw_conv3x3_nhwc_ex", "fw_u8_to_rgb_f32", "fw_resize_bilinear_f32", "fw_ifnet_build_x", "fw_unshuffle2_cast",
+    "fw_depth_to_space4_f32", "fw_ifnet_accumulate", "fw_ifnet_blend",
 ]
 
 
@@ -106,6 +108,27 @@ def _declare_tap(lib: C.CDLL) -> None:
     lib.fw_strength_blend_u8.argtypes = [vp, vp, f64, sz, vp, vp]
 
 
+def _declare_ifnet(lib: C.CDLL) -> None:
+    vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
+    lib.fw_conv3x3_nhwc_ex.restype = i32
+    lib.fw_conv3x3_nhwc_ex.argtypes = [i32, vp, i32, C.c_long, i32, i32, i32, vp, vp, i32, i32, i32, vp, f32, vp, f32, vp, i32,
+                                       i32, i32, vp, i32, C.c_long, i32, vp, vp]
+    lib.fw_u8_to_rgb_f32.restype = i32
+    lib.fw_u8_to_rgb_f32.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    lib.fw_resize_bilinear_f32.restype = i32
+    lib.fw_resize_bilinear_f32.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, i32, f32, f32, vp]
+    lib.fw_ifnet_build_x.restype = i32
+    lib.fw_ifnet_build_x.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp, vp]
+    lib.fw_unshuffle2_cast.restype = i32
+    lib.fw_unshuffle2_cast.argtypes = [i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]
+    lib.fw_depth_to_space4_f32.restype = i32
+    lib.fw_depth_to_space4_f32.argtypes = [vp, i32, i32, i32, vp, vp]
+    lib.fw_ifnet_accumulate.restype = i32
+    lib.fw_ifnet_accumulate.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp, i32, vp]
+    lib.fw_ifnet_blend.restype = i32
+    lib.fw_ifnet_blend.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
+
+
 def load() -> C.CDLL:
     """Load the shared library (once).  Raises FramewrightHipError when it is absent — build it with
     ``python __graft_entry__.py build`` (hipcc, gfx950)."""
@@ -129,6 +152,7 @@ def load() -> C.CDLL:
             raise FramewrightHipError(FW_ERR_INTERNAL, f"cannot load {LIB_PATH}: {e}") from e
         _declare(lib)
         _declare_tap(lib)
+        _declare_ifnet(lib)
         _lib = lib
         return lib
 

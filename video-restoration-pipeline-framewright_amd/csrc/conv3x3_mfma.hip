@@ -362,15 +362,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(const ConvParams p
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const size_t nat = ((((((size_t)t * 4 + wave) * 4 + row) * CT + ct) * 4 + g) * 64 + lane) * 4;
-                        const size_t lin = pix * NC + 32 * ct + 8 * g + 4 * h;
+                        const size_t lin = pix * (p.f32_cstride ? p.f32_cstride : NC) + p.f32_coff + 32 * ct + 8 * g + 4 * h;
                         const size_t fo = p.f32_native ? nat : lin;
                         const bool fok = p.f32_native || inside;
                         f32x4 o = {acc[row][ct][4 * g], acc[row][ct][4 * g + 1], acc[row][ct][4 * g + 2],
                                    acc[row][ct][4 * g + 3]};
                         if constexpr (EPI == EPI_RESIDUAL) {
                             if (fok) {
+                                if (p.chan_scale) o = o * *reinterpret_cast<const f32x4*>(p.chan_scale + 32 * ct + 8 * g + 4 * h);
                                 o = o * p.s1 + *reinterpret_cast<const f32x4*>(p.res1 + fo);
                                 if (p.res2) o = o * p.s2 + *reinterpret_cast<const f32x4*>(p.res2 + fo);
+                                if (p.post_act) {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.2f * o[j]);
+                                }
                             }
                         } else {
                             if (p.act) {

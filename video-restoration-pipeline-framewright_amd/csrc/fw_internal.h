@@ -44,6 +44,10 @@ struct ConvParams {
     int img_H, img_W;      // EPI_IMAGE: size of the stored image (crop of the H x W conv output; mod-pad removal)
     int act;               // 1 = LeakyReLU(0.2) (EPI_STORE only)
     int upsample2x;        // 1 = input is nearest-neighbour x2 upsampled on the fly
+    const float* chan_scale;  // EPI_RESIDUAL: optional per-output-channel factor, y = (acc+bias)*chan_scale[n]*s1 + res1
+    int post_act;          // EPI_RESIDUAL: 1 = LeakyReLU(0.2) after the residual add (IFNet ResConv)
+    int f32_cstride;       // NHWC fp32 side buffers: floats per pixel (0 = 32*cout_tiles) and first channel
+    int f32_coff;
     int f32_native;        // 1: res1/res2/out_f32 use the accumulator-native layout (see f32_native_elems)
     const void* zeros;     // >= 16 bytes of zeros in device memory (set by launch_conv3x3)
 };

@@ -1,0 +1,310 @@
+// IFNet (RIFE v4.6) building blocks that are not convolutions (kernel set K7 of SURVEY.md §8a): bilinear resize,
+// backward warp (grid_sample bilinear / border / align_corners=True), sigmoid-mask blend, pixel (un)shuffle glue.
+//
+// The reference only shells out to the external binary `rife-ncnn-vulkan` (reference
+// src/framewright/processors/interpolation.py:628-650); the arithmetic restated here is IFNet_HDv3 v4.6 as recorded in
+// SURVEY.md §A.5 and in oracle/ifnet_ref.py ("parity vs upstream unpinned").  All tensors are fp32 NHWC with a handful
+// of channels (image 3, flow 4, mask 1): HBM-bound byte work, one thread per output pixel, no LDS.
+#include "fw_internal.h"
+#include "../../include/framewright_hip.h"
+
+namespace fw {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T>
+__device__ __forceinline__ T cvt(float f);
+template <>
+__device__ __forceinline__ __bf16 cvt<__bf16>(float f) { return (__bf16)f; }
+template <>
+__device__ __forceinline__ _Float16 cvt<_Float16>(float f) { return (_Float16)f; }
+
+// uint8 BGR H x W -> fp32 RGB/255 [Hp][Wp][3], zero outside (Practical-RIFE pads bottom/right to a multiple of 32)
+__global__ __launch_bounds__(256) void u8_to_rgb_f32_kernel(const uint8_t* __restrict__ in, int H, int W, int Hp, int Wp,
+                                                            float* out) {
+    const long n = (long)Hp * Wp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / Wp), x = (int)(i - (long)y * Wp);
+        float r = 0, g = 0, b = 0;
+        if (y < H && x < W) {
+            const uint8_t* px = in + ((size_t)y * W + x) * 3;
+            b = px[0] / 255.0f;
+            g = px[1] / 255.0f;
+            r = px[2] / 255.0f;
+        }
+        out[i * 3 + 0] = r;
+        out[i * 3 + 1] = g;
+        out[i * 3 + 2] = b;
+    }
+}
+
+// torch F.interpolate(mode="bilinear", align_corners=False, scale_factor=sf): src = (dst + 0.5) / sf - 0.5, clamped at 0
+__device__ __forceinline__ void bilin_setup(int d, float inv_sf, int n, int* i0, int* i1, float* w1) {
+    float s = ((float)d + 0.5f) * inv_sf - 0.5f;
+    if (s < 0.f) s = 0.f;
+    int a = (int)s;
+    if (a > n - 1) a = n - 1;
+    *i0 = a;
+    *i1 = a + 1 < n ? a + 1 : n - 1;
+    *w1 = s - (float)a;
+}
+
+// dst[y][x][dst_coff + c] = mul * bilinear(src[..][c]), c < C
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ src, int Hs, int Ws, int C, float* dst,
+                                                              int Hd, int Wd, int dst_cstride, int dst_coff, float inv_sf,
+                                                              float mul) {
+    const long n = (long)Hd * Wd;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / Wd), x = (int)(i - (long)y * Wd);
+        int y0, y1, x0, x1;
+        float wy, wx;
+        bilin_setup(y, inv_sf, Hs, &y0, &y1, &wy);
+        bilin_setup(x, inv_sf, Ws, &x0, &x1, &wx);
+        const float* p00 = src + ((size_t)y0 * Ws + x0) * C;
+        const float* p01 = src + ((size_t)y0 * Ws + x1) * C;
+        const float* p10 = src + ((size_t)y1 * Ws + x0) * C;
+        const float* p11 = src + ((size_t)y1 * Ws + x1) * C;
+        float* o = dst + (size_t)i * dst_cstride + dst_coff;
+        for (int c = 0; c < C; ++c) {
+            const float top = p00[c] * (1.f - wx) + p01[c] * wx;
+            const float bot = p10[c] * (1.f - wx) + p11[c] * wx;
+            o[c] = (top * (1.f - wy) + bot * wy) * mul;
+        }
+    }
+}
+
+// grid_sample(img, base + flow, bilinear, padding_mode='border', align_corners=True) with flow in pixels:
+// sample position (x + fx, y + fy) clamped to the image, then bilinear.
+__device__ __forceinline__ void warp_px(const float* __restrict__ img, int H, int W, float sx, float sy, float* o) {
+    sx = fminf(fmaxf(sx, 0.f), (float)(W - 1));
+    sy = fminf(fmaxf(sy, 0.f), (float)(H - 1));
+    const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
+    const int x1 = x0 + 1 < W ? x0 + 1 : W - 1, y1 = y0 + 1 < H ? y0 + 1 : H - 1;
+    const float wx = sx - (float)x0, wy = sy - (float)y0;
+    const float* p00 = img + ((size_t)y0 * W + x0) * 3;
+    const float* p01 = img + ((size_t)y0 * W + x1) * 3;
+    const float* p10 = img + ((size_t)y1 * W + x0) * 3;
+    const float* p11 = img + ((size_t)y1 * W + x1) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        o[c] = (p00[c] * (1.f - wx) + p01[c] * wx) * (1.f - wy) + (p10[c] * (1.f - wx) + p11[c] * wx) * wy;
+}
+
+// X = cat(warp(I0, flow[:2]), warp(I1, flow[2:4]), timestep, mask)  (8 ch), or cat(I0, I1, timestep) (7 ch) when flow == 0
+__global__ __launch_bounds__(256) void ifnet_build_x_kernel(const float* __restrict__ i0, const float* __restrict__ i1,
+                                                            const float* __restrict__ flow, const float* __restrict__ mask,
+                                                            int H, int W, float timestep, float* X) {
+    const long n = (long)H * W;
+    const int C = flow ? 8 : 7;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W), x = (int)(i - (long)y * W);
+        float* o = X + (size_t)i * C;
+        if (flow) {
+            const float* f = flow + (size_t)i * 4;
+            warp_px(i0, H, W, x + f[0], y + f[1], o);
+            warp_px(i1, H, W, x + f[2], y + f[3], o + 3);
+            o[6] = timestep;
+            o[7] = mask[i];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                o[c] = i0[i * 3 + c];
+                o[3 + c] = i1[i * 3 + c];
+            }
+            o[6] = timestep;
+        }
+    }
+}
+
+// pixel_unshuffle(2) + cast: src [h][w][C] (fp32 or operand-typed) -> dst typed [h/2][w/2][Cpad], channel c*4 + dy*2 + dx,
+// zero for channels >= 4*C.  (Front end of the stride-2 convs, which run as 3x3 convs on the unshuffled tensor.)
+template <typename T, typename S>
+__global__ __launch_bounds__(256) void unshuffle_cast_kernel(const S* __restrict__ src, int h, int w, int C, int src_cstride,
+                                                             T* dst, int Cpad) {
+    const int ho = h / 2, wo = w / 2;
+    const long n = (long)ho * wo * Cpad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % Cpad);
+        const long pix = i / Cpad;
+        const int y = (int)(pix / wo), x = (int)(pix - (long)y * wo);
+        float v = 0.f;
+        if (ch < 4 * C) {
+            const int c = ch >> 2, dy = (ch >> 1) & 1, dx = ch & 1;
+            v = (float)src[((size_t)(2 * y + dy) * w + (2 * x + dx)) * src_cstride + c];
+        }
+        dst[i] = cvt<T>(v);
+    }
+}
+
+// lastconv glue: src fp32 [h][w][cs], channel n = ((c6*4 + qy*2 + qx)*4 + py*2 + px)  ->  dst [4h][4w][6]:
+// ConvTranspose2d(k4,s2,p1) computed as a 3x3 conv with 4 parity groups (py,px), followed by PixelShuffle(2) (qy,qx).
+__global__ __launch_bounds__(256) void depth_to_space4_kernel(const float* __restrict__ src, int h, int w, int cs, float* dst) {
+    const long n = (long)h * w * 96;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % 96);
+        const long pix = i / 96;
+        const int y = (int)(pix / w), x = (int)(pix - (long)y * w);
+        const int px = ch & 1, py = (ch >> 1) & 1, co = ch >> 2;
+        const int qx = co & 1, qy = (co >> 1) & 1, c6 = co >> 2;
+        dst[((size_t)(4 * y + 2 * py + qy) * (4 * w) + (4 * x + 2 * px + qx)) * 6 + c6] = src[pix * cs + ch];
+    }
+}
+
+// tmp_s [hs][ws][6] (low resolution) -> full resolution by bilinear x scale; flow (+)= tmp[:4] * scale, mask (+)= tmp[4]
+__global__ __launch_bounds__(256) void ifnet_accumulate_kernel(const float* __restrict__ tmp, int hs, int ws, int H, int W,
+                                                               float scale, float* flow, float* mask, int first) {
+    const long n = (long)H * W;
+    const float inv_sf = 1.0f / scale;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W), x = (int)(i - (long)y * W);
+        int y0, y1, x0, x1;
+        float wy, wx;
+        bilin_setup(y, inv_sf, hs, &y0, &y1, &wy);
+        bilin_setup(x, inv_sf, ws, &x0, &x1, &wx);
+        const float* p00 = tmp + ((size_t)y0 * ws + x0) * 6;
+        const float* p01 = tmp + ((size_t)y0 * ws + x1) * 6;
+        const float* p10 = tmp + ((size_t)y1 * ws + x0) * 6;
+        const float* p11 = tmp + ((size_t)y1 * ws + x1) * 6;
+        float v[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+            v[c] = (p00[c] * (1.f - wx) + p01[c] * wx) * (1.f - wy) + (p10[c] * (1.f - wx) + p11[c] * wx) * wy;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) flow[i * 4 + c] = (first ? 0.f : flow[i * 4 + c]) + v[c] * scale;
+        mask[i] = (first ? 0.f : mask[i]) + v[4];
+    }
+}
+
+// merged = warp(I0, flow[:2]) * sigmoid(mask) + warp(I1, flow[2:4]) * (1 - sigmoid(mask)); crop to H x W;
+// optional fp32 RGB; uint8 BGR = round_half_even(clamp(x, 0, 1) * 255)
+__global__ __launch_bounds__(256) void ifnet_blend_kernel(const float* __restrict__ i0, const float* __restrict__ i1,
+                                                          const float* __restrict__ flow, const float* __restrict__ mask,
+                                                          int Hp, int Wp, int H, int W, uint8_t* out_bgr, float* out_rgb) {
+    const long n = (long)H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W), x = (int)(i - (long)y * W);
+        const size_t ip = (size_t)y * Wp + x;
+        const float* f = flow + ip * 4;
+        float a[3], b[3];
+        warp_px(i0, Hp, Wp, x + f[0], y + f[1], a);
+        warp_px(i1, Hp, Wp, x + f[2], y + f[3], b);
+        const float m = 1.0f / (1.0f + expf(-mask[ip]));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = a[c] * m + b[c] * (1.f - m);
+            if (out_rgb) out_rgb[i * 3 + c] = v;
+            if (out_bgr) out_bgr[i * 3 + (2 - c)] = (uint8_t)rintf(fminf(fmaxf(v, 0.f), 1.f) * 255.f);
+        }
+    }
+}
+
+static int grid_for(long n) { return (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); }
+
+}  // namespace fw
+
+using namespace fw;
+
+namespace {
+int fail(int code, const std::string& m) {
+    fw::last_error_ref() = m;
+    return code;
+}
+#define FW_LAUNCHED()                                                            \
+    do {                                                                         \
+        hipError_t e_ = hipGetLastError();                                       \
+        if (e_ != hipSuccess) return fail(FW_ERR_HIP, hipGetErrorString(e_));    \
+    } while (0)
+}  // namespace
+
+extern "C" {
+
+int fw_u8_to_rgb_f32(const uint8_t* in_bgr, int height, int width, int padded_height, int padded_width, float* out,
+                     void* stream) {
+    if (!in_bgr || !out || height < 1 || width < 1 || padded_height < height || padded_width < width)
+        return fail(FW_ERR_INVALID, "fw_u8_to_rgb_f32: bad argument");
+    const long n = (long)padded_height * padded_width;
+    hipLaunchKernelGGL(u8_to_rgb_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, in_bgr, height, width,
+                       padded_height, padded_width, out);
+    FW_LAUNCHED();
+    return FW_OK;
+}
+
+int fw_resize_bilinear_f32(const float* src, int src_h, int src_w, int channels, float* dst, int dst_h, int dst_w,
+                           int dst_cstride, int dst_coff, float scale_factor, float mul, void* stream) {
+    if (!src || !dst || src_h < 1 || src_w < 1 || dst_h < 1 || dst_w < 1 || channels < 1 || dst_cstride < dst_coff + channels ||
+        !(scale_factor > 0.f))
+        return fail(FW_ERR_INVALID, "fw_resize_bilinear_f32: bad argument");
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for((long)dst_h * dst_w)), dim3(256), 0, (hipStream_t)stream, src,
+                       src_h, src_w, channels, dst, dst_h, dst_w, dst_cstride, dst_coff, 1.0f / scale_factor, mul);
+    FW_LAUNCHED();
+    return FW_OK;
+}
+
+int fw_ifnet_build_x(const float* img0, const float* img1, const float* flow, const float* mask, int height, int width,
+                     float timestep, float* x, void* stream) {
+    if (!img0 || !img1 || !x || height < 1 || width < 1 || ((flow == nullptr) != (mask == nullptr)))
+        return fail(FW_ERR_INVALID, "fw_ifnet_build_x: bad argument");
+    hipLaunchKernelGGL(ifnet_build_x_kernel, dim3(grid_for((long)height * width)), dim3(256), 0, (hipStream_t)stream, img0,
+                       img1, flow, mask, height, width, timestep, x);
+    FW_LAUNCHED();
+    return FW_OK;
+}
+
+int fw_unshuffle2_cast(int dtype, const void* src, int src_is_f32, int height, int width, int channels, int src_cstride,
+                       void* dst, int dst_channels, void* stream) {
+    if (!src || !dst || height < 2 || width < 2 || (height & 1) || (width & 1) || channels < 1 || src_cstride < channels ||
+        dst_channels < 4 * channels || (dtype != FW_DTYPE_BF16 && dtype != FW_DTYPE_F16))
+        return fail(FW_ERR_INVALID, "fw_unshuffle2_cast: bad argument");
+    const long n = (long)(height / 2) * (width / 2) * dst_channels;
+    dim3 g(grid_for(n)), b(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == FW_DTYPE_BF16) {
+        if (src_is_f32)
+            hipLaunchKernelGGL((unshuffle_cast_kernel<__bf16, float>), g, b, 0, st, (const float*)src, height, width, channels,
+                               src_cstride, (__bf16*)dst, dst_channels);
+        else
+            hipLaunchKernelGGL((unshuffle_cast_kernel<__bf16, __bf16>), g, b, 0, st, (const __bf16*)src, height, width,
+                               channels, src_cstride, (__bf16*)dst, dst_channels);
+    } else {
+        if (src_is_f32)
+            hipLaunchKernelGGL((unshuffle_cast_kernel<_Float16, float>), g, b, 0, st, (const float*)src, height, width,
+                               channels, src_cstride, (_Float16*)dst, dst_channels);
+        else
+            hipLaunchKernelGGL((unshuffle_cast_kernel<_Float16, _Float16>), g, b, 0, st, (const _Float16*)src, height, width,
+                               channels, src_cstride, (_Float16*)dst, dst_channels);
+    }
+    FW_LAUNCHED();
+    return FW_OK;
+}
+
+int fw_depth_to_space4_f32(const float* src, int height, int width, int src_cstride, float* dst, void* stream) {
+    if (!src || !dst || height < 1 || width < 1 || src_cstride < 96) return fail(FW_ERR_INVALID, "fw_depth_to_space4_f32: bad argument");
+    hipLaunchKernelGGL(depth_to_space4_kernel, dim3(grid_for((long)height * width * 96)), dim3(256), 0, (hipStream_t)stream,
+                       src, height, width, src_cstride, dst);
+    FW_LAUNCHED();
+    return FW_OK;
+}
+
+int fw_ifnet_accumulate(const float* tmp, int tmp_h, int tmp_w, int height, int width, float scale, float* flow, float* mask,
+                        int first, void* stream) {
+    if (!tmp || !flow || !mask || tmp_h < 1 || tmp_w < 1 || height < 1 || width < 1 || !(scale >= 1.f))
+        return fail(FW_ERR_INVALID, "fw_ifnet_accumulate: bad argument");
+    hipLaunchKernelGGL(ifnet_accumulate_kernel, dim3(grid_for((long)height * width)), dim3(256), 0, (hipStream_t)stream, tmp,
+                       tmp_h, tmp_w, height, width, scale, flow, mask, first);
+    FW_LAUNCHED();
+    return FW_OK;
+}
+
+int fw_ifnet_blend(const float* img0, const float* img1, const float* flow, const float* mask, int padded_height,
+                   int padded_width, int height, int width, uint8_t* out_bgr, float* out_rgb_f32, void* stream) {
+    if (!img0 || !img1 || !flow || !mask || (!out_bgr && !out_rgb_f32) || height < 1 || width < 1 || padded_height < height ||
+        padded_width < width)
+        return fail(FW_ERR_INVALID, "fw_ifnet_blend: bad argument");
+    hipLaunchKernelGGL(ifnet_blend_kernel, dim3(grid_for((long)height * width)), dim3(256), 0, (hipStream_t)stream, img0, img1,
+                       flow, mask, padded_height, padded_width, height, width, out_bgr, out_rgb_f32);
+    FW_LAUNCHED();
+    return FW_OK;
+}
+
+}  // extern "C"

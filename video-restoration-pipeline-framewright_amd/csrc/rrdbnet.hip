@@ -521,6 +521,16 @@ int fw_conv3x3_nhwc(int dtype, const void* x, int in_cstride, long in_plane_stri
                     const void* packed_weight, const float* bias, int cout_tiles, int act_lrelu, int upsample2x,
                     const float* res1, float s1, const float* res2, float s2, void* out, int out_cstride,
                     long out_plane_stride, int out_coff, float* out_f32, void* stream) {
+    return fw_conv3x3_nhwc_ex(dtype, x, in_cstride, in_plane_stride, cin_chunks, H, W, packed_weight, bias, cout_tiles,
+                              act_lrelu, upsample2x, res1, s1, res2, s2, nullptr, 0, 0, 0, out, out_cstride,
+                              out_plane_stride, out_coff, out_f32, stream);
+}
+
+int fw_conv3x3_nhwc_ex(int dtype, const void* x, int in_cstride, long in_plane_stride, int cin_chunks, int H, int W,
+                       const void* packed_weight, const float* bias, int cout_tiles, int act_lrelu, int upsample2x,
+                       const float* res1, float s1, const float* res2, float s2, const float* chan_scale, int post_act,
+                       int f32_cstride, int f32_coff, void* out, int out_cstride, long out_plane_stride, int out_coff,
+                       float* out_f32, void* stream) {
     if (!x || !packed_weight || !bias) return fail(FW_ERR_INVALID, "fw_conv3x3_nhwc: NULL argument");
     if (dtype != FW_DTYPE_BF16 && dtype != FW_DTYPE_F16) return fail(FW_ERR_INVALID, "fw_conv3x3_nhwc: bad dtype");
     if (cout_tiles != 1 && cout_tiles != 2) return fail(FW_ERR_INVALID, "fw_conv3x3_nhwc: cout_tiles must be 1 or 2");
@@ -547,6 +557,10 @@ int fw_conv3x3_nhwc(int dtype, const void* x, int in_cstride, long in_plane_stri
         p.s2 = s2;
         p.act = act_lrelu;
         p.upsample2x = upsample2x;
+        p.chan_scale = chan_scale;
+        p.post_act = post_act;
+        p.f32_cstride = f32_cstride;
+        p.f32_coff = f32_coff;
         launch_conv3x3((DType)dtype, cout_tiles, res1 ? EPI_RESIDUAL : EPI_STORE, p, (hipStream_t)stream);
     });
 }

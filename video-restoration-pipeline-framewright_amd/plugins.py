@@ -110,6 +110,7 @@ except Exception:  # noqa: BLE001
             meta = PluginMetadata(name=name, version=version, description=description, capabilities=capabilities or set(),
                                   **metadata_kwargs)
             cls.get_metadata = classmethod(lambda c: meta)
+            cls.__abstractmethods__ = frozenset(getattr(cls, "__abstractmethods__", frozenset()) - {"get_metadata"})
             return cls
         return decorator
 
@@ -121,9 +122,22 @@ def _gpu_id(device: str) -> int:
     return int(device.split(":")[1]) if ":" in device else 0
 
 
-@plugin(name="realesrgan_mi355x", version="0.1.0", description="Real-ESRGAN x2/x4 on MI355X (hand-written HIP kernels)",
-        capabilities={PluginCapability.UPSCALE}, supports_cpu=False, min_vram_mb=2000)
+# NOTE: the reference's @plugin decorator (plugins/base.py:328-355) assigns get_metadata AFTER the class is created, when
+# ABCMeta has already frozen __abstractmethods__, so a class that relies on it alone cannot be instantiated.  The
+# plugins below therefore define get_metadata themselves (the decorator stays available for third parties).
+_SR_META = PluginMetadata(name="realesrgan_mi355x", version="0.1.0",
+                          description="Real-ESRGAN x2/x4 on MI355X (hand-written HIP kernels)",
+                          capabilities={PluginCapability.UPSCALE}, supports_cpu=False, min_vram_mb=2000)
+_TAP_META = PluginMetadata(name="tap_denoise_mi355x", version="0.1.0",
+                           description="NAFNet temporal denoise on MI355X (hand-written HIP kernels)",
+                           capabilities={PluginCapability.DENOISE}, supports_cpu=False, min_vram_mb=2000)
+
+
 class RealESRGANPlugin(ProcessorPlugin):
+    @classmethod
+    def get_metadata(cls) -> PluginMetadata:
+        return _SR_META
+
     def _on_initialize(self) -> None:
         from . import realesrgan as R
         self._cfg = R.PyTorchESRGANConfig(model_name=self._settings.get("model_name", "RealESRGAN_x4plus"),
@@ -144,9 +158,11 @@ class RealESRGANPlugin(ProcessorPlugin):
         return 10.0
 
 
-@plugin(name="tap_denoise_mi355x", version="0.1.0", description="NAFNet temporal denoise on MI355X (hand-written HIP kernels)",
-        capabilities={PluginCapability.DENOISE}, supports_cpu=False, min_vram_mb=2000)
 class TAPDenoisePlugin(ProcessorPlugin):
+    @classmethod
+    def get_metadata(cls) -> PluginMetadata:
+        return _TAP_META
+
     def _on_initialize(self) -> None:
         from . import tap_denoise as T
         self._dn = T.TAPDenoiser(T.TAPDenoiseConfig(temporal_window=int(self._settings.get("temporal_window", 5)),

@@ -154,3 +154,45 @@ def synthetic_nafnet_state(width: int = 64, middle_blk_num: int = 12, enc_blk_nu
                 v = v * 0.1
         sd[key] = v.astype(np.float32)
     return sd
+
+
+IFNET_CHANNELS = (192, 128, 96, 64)   # IFNet_HDv3 v4.6
+IFNET_SCALES = (8, 4, 2, 1)
+
+
+def ifnet_tensor_shapes() -> List[Tuple[str, Tuple[int, ...]]]:
+    out: List[Tuple[str, Tuple[int, ...]]] = []
+    for i, c in enumerate(IFNET_CHANNELS):
+        cin = 7 if i == 0 else 12
+        p = f"block{i}."
+        out += [(p + "conv0.0.0.weight", (c // 2, cin, 3, 3)), (p + "conv0.0.0.bias", (c // 2,)),
+                (p + "conv0.1.0.weight", (c, c // 2, 3, 3)), (p + "conv0.1.0.bias", (c,))]
+        for j in range(8):
+            out += [(f"{p}convblock.{j}.conv.weight", (c, c, 3, 3)), (f"{p}convblock.{j}.conv.bias", (c,)),
+                    (f"{p}convblock.{j}.beta", (1, c, 1, 1))]
+        out += [(p + "lastconv.0.weight", (c, 24, 4, 4)), (p + "lastconv.0.bias", (24,))]
+    return out
+
+
+def synthetic_ifnet_state(seed: int = 2468, flow_gain: float = 1.0) -> Dict[str, np.ndarray]:
+    """Seeded IFNet weights: PyTorch default init restated; ResConv beta U(0.2, 0.6); lastconv scaled so that the flow
+    increments are a few pixels at most (a trained net's are) and the masks moderate; ``flow_gain`` scales them
+    (tests use a larger gain to exercise multi-pixel warps)."""
+    rng = np.random.default_rng(seed)
+    sd: Dict[str, np.ndarray] = {}
+    shapes = dict(ifnet_tensor_shapes())
+    for key, shape in ifnet_tensor_shapes():
+        if key.endswith("beta"):
+            v = rng.uniform(0.2, 0.6, size=shape)
+        else:
+            wshape = shape if key.endswith("weight") else shapes[key[:-4] + "weight"]
+            if "lastconv" in key:
+                fan_in = wshape[0] * 4  # transposed conv: 2x2 taps of c inputs contribute to an output
+            else:
+                fan_in = int(np.prod(wshape[1:]))
+            bound = 1.0 / np.sqrt(fan_in)
+            v = rng.uniform(-bound, bound, size=shape)
+            if "lastconv" in key:
+                v = v * 0.5 * flow_gain
+        sd[key] = v.astype(np.float32)
+    return sd
