@@ -191,7 +191,7 @@ Plan make_plan(const fw_nafnet* n, int H, int W) {
     p.T2 = take(M0 * n->width * 2 * 2);
     p.T3 = take(M0 * n->width * 2);
     p.csum = take((size_t)1024 * 1024 * 4);  // dwconv partial sums [<=1024 blocks][<=1024 channels]
-    p.sca = take(4096);
+    p.sca = take(2 * 1024 * 4);  // SCA scale [C] + pooled mean [C]
     p.cat64 = take(M0 * n->width * 2);
     p.rgb = take(M0 * 3 * 4);
     p.total = o;

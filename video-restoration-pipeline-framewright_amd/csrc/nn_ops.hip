@@ -402,18 +402,14 @@ __global__ __launch_bounds__(256) void dwconv3x3_gate_kernel(const T* __restrict
     const long total = (long)H * W * groups;
     const int g = threadIdx.x % groups;
     float cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    float wr[2][8][9];
     float br[2][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         br[0][j] = bdw[g * 8 + j];
         br[1][j] = bdw[C + g * 8 + j];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            wr[0][j][t] = wdw[(g * 8 + j) * 9 + t];
-            wr[1][j][t] = wdw[(C + g * 8 + j) * 9 + t];
-        }
     }
+    const float* w1p = wdw + (size_t)(g * 8) * 9;        // this thread's 8 + 8 filters (L1 resident: 72 floats each)
+    const float* w2p = wdw + (size_t)(C + g * 8) * 9;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const long pix = idx / groups;
         const int yy = (int)(pix / W), xx = (int)(pix - (long)yy * W);
@@ -438,8 +434,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_gate_kernel(const T* __restrict
                 const int tap = (dy + 1) * 3 + (dx + 1);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    a1[j] += f1[j] * wr[0][j][tap];
-                    a2[j] += f2[j] * wr[1][j][tap];
+                    a1[j] += f1[j] * w1p[j * 9 + tap];
+                    a2[j] += f2[j] * w2p[j * 9 + tap];
                 }
             }
         }
@@ -491,28 +487,35 @@ void launch_dwconv3x3_gate(DType dt, const void* x, int H, int W, int C, const f
     FW_HIP_CHECK(hipGetLastError());
 }
 
-// SCA: s[n] = b[n] + sum_k W[n][k] * mean[k], mean[k] = (sum over blocks of partial[b][k]) / HW, summed in block order
-// (deterministic).  One wave per output channel.
-__global__ __launch_bounds__(256) void sca_kernel(const float* __restrict__ partial, int nblocks, float inv_hw, int C,
-                                                  const float* w, const float* b, float* s) {
+// SCA: mean[k] = (sum over blocks of partial[b][k]) / HW, summed in block order (deterministic); then
+// s[n] = b[n] + sum_k W[n][k] * mean[k], one wave per output channel.
+__global__ __launch_bounds__(256) void sca_mean_kernel(const float* __restrict__ partial, int nblocks, float inv_hw, int C,
+                                                       float* mean) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= C) return;
+    float m = 0.f;
+    for (int q = 0; q < nblocks; ++q) m += partial[(long)q * C + k];
+    mean[k] = m * inv_hw;
+}
+
+__global__ __launch_bounds__(256) void sca_kernel(const float* __restrict__ mean, int C, const float* w, const float* b,
+                                                  float* s) {
     const int lane = threadIdx.x & 63;
     const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (n >= C) return;
     float a = 0.f;
-    for (int k = lane; k < C; k += 64) {
-        float m = 0.f;
-        for (int q = 0; q < nblocks; ++q) m += partial[(long)q * C + k];
-        a += w[(long)n * C + k] * (m * inv_hw);
-    }
+    for (int k = lane; k < C; k += 64) a += w[(long)n * C + k] * mean[k];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
     if (lane == 0) s[n] = a + b[n];
 }
 
+// `s` must have room for 2*C floats: [0, C) receives the scale, [C, 2C) is scratch for the pooled mean.
 void launch_sca(const float* partial, int nblocks, long HW, int C, const float* w, const float* b, float* s,
                 hipStream_t st) {
-    hipLaunchKernelGGL(sca_kernel, dim3((C * 64 + 255) / 256), dim3(256), 0, st, partial, nblocks, 1.0f / (float)HW, C, w, b,
-                       s);
+    float* mean = s + C;
+    hipLaunchKernelGGL(sca_mean_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, nblocks, 1.0f / (float)HW, C, mean);
+    hipLaunchKernelGGL(sca_kernel, dim3((C * 64 + 255) / 256), dim3(256), 0, st, (const float*)mean, C, w, b, s);
     FW_HIP_CHECK(hipGetLastError());
 }
 
