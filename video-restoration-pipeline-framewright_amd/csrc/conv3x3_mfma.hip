@@ -66,7 +66,9 @@ constexpr int ROW_PIECES = HALO_W * 4;                    // 136 16-byte pieces 
 constexpr int ACT_PIECES = HALO_H * ROW_PIECES;           // 2448 pieces per 32-channel chunk
 constexpr int ACT_INSTR = 40;                            // wave-instructions of 1 KiB per chunk (39 used + 1 pad)
 constexpr int ACT_REGION = ACT_INSTR * 64;                // 2560 pieces = 40 KiB per stage
-constexpr int ACT_ITERS = ACT_INSTR / 4;                  // 10 per wave, every wave issues all of them
+constexpr int NWAVES = 8;                                 // 512 threads: two waves per SIMD hide each other's stalls
+constexpr int RPW = TILE_H / NWAVES;                      // output rows per wave (2)
+constexpr int ACT_ITERS = ACT_INSTR / NWAVES;             // 5 per wave, every wave issues all of them
 constexpr int W_FRAGS = 18;                               // 9 taps x 2 k-steps of 16, per cout tile
 
 // LDS image of one activation chunk: [halo row][halo px][4 slots of 16 B]; slot s (= 8 channels) of pixel p is
@@ -81,10 +83,10 @@ constexpr int W_FRAGS = 18;                               // 9 taps x 2 k-steps 
 template <int CT>
 struct Smem {
     static constexpr int NA = CT == 1 ? 3 : 2;                  // activation stages in flight
-    static constexpr int W_ITERS = (W_FRAGS * CT + 3) / 4;      // weight DMAs per wave per stage (5 or 9)
-    static constexpr int W_REGION = W_ITERS * 4 * 64;           // pieces per weight stage (incl. pad fragments)
+    static constexpr int W_ITERS = (W_FRAGS * CT + NWAVES - 1) / NWAVES;  // weight DMAs per wave per stage (<= 3 or 5)
+    static constexpr int W_REGION = W_FRAGS * CT * 64;          // pieces per weight stage
     static constexpr int W_BASE = NA * ACT_REGION;
-    static constexpr int TOTAL = NA * ACT_REGION + 2 * W_REGION;  // CT=1: 160 KiB exactly; CT=2: 152 KiB
+    static constexpr int TOTAL = NA * ACT_REGION + 2 * W_REGION;  // CT=1: 156 KiB; CT=2: 152 KiB
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -104,18 +106,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
         : "memory");
 }
 
-// Fragments of one (k-step, dx) group: the wave's 6 halo rows at column offset dx and the 3 (dy) weight
-// fragments per cout tile -> 12*CT MFMAs.
+// Fragments of one (k-step, dx) group: the wave's RPW+2 halo rows at column offset dx and the 3 (dy) weight
+// fragments per cout tile -> 3*RPW*CT MFMAs.
 template <int CT>
 struct Frags {
-    uint4 x[6];
+    uint4 x[RPW + 2];
     uint4 w[3][CT];
 };
 
 #define FW_SB() __builtin_amdgcn_sched_barrier(0)
 
 template <typename T, int CT, int EPI>
-__global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const ConvParams p) {
     using SM = Smem<CT>;
     __shared__ __attribute__((aligned(16))) uint4 lds[SM::TOTAL];
     constexpr int NA = SM::NA;
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(const ConvParams p
     int rp[ACT_ITERS];   // (halo row << 8) | halo px, or -1 for the pad pieces
 #pragma unroll
     for (int i = 0; i < ACT_ITERS; ++i) {
-        const int idx = (wave + 4 * i) * 64 + lane;
+        const int idx = (wave + NWAVES * i) * 64 + lane;
         const int row = idx / ROW_PIECES;
         const int rm = idx - row * ROW_PIECES;
         const int px = rm >> 2;
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(const ConvParams p
     // DMA number i (0..ACT_ITERS-1) of the next activation item
     auto issue_act_one = [&](int i) {
         if (i == 0 && a_c == 0) plan_tile();
-        glds16(src[i], lds_base + (unsigned)((a_n % NA) * ACT_REGION + (wave + 4 * i) * 64) * 16u);
+        glds16(src[i], lds_base + (unsigned)((a_n % NA) * ACT_REGION + (wave + NWAVES * i) * 64) * 16u);
         src[i] += inc[i];
         if (i == ACT_ITERS - 1) {
             ++a_n;
@@ -195,32 +197,34 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(const ConvParams p
             }
         }
     };
-    // DMA number i (0..W_ITERS-1) of the weights of chunk c into weight stage ws (pad fragments re-load fragment 0)
+    // DMA number i (0..W_ITERS-1) of the weights of chunk c into weight stage ws.  Waves issue a different number of
+    // these (18*CT fragments over 8 waves); that is fine because they are OLDER than the counted activation DMAs.
     auto issue_w_one = [&](int i, int c, int ws) {
-        const int f = wave + 4 * i;
-        glds16(w_b + (size_t)c * (W_FRAGS * CT * 1024) + (f < W_FRAGS * CT ? f : 0) * 1024,
-               lds_base + (unsigned)(SM::W_BASE + ws * SM::W_REGION + f * 64) * 16u);
+        const int f = wave + NWAVES * i;
+        if (f < W_FRAGS * CT)
+            glds16(w_b + (size_t)c * (W_FRAGS * CT * 1024) + f * 1024,
+                   lds_base + (unsigned)(SM::W_BASE + ws * SM::W_REGION + f * 64) * 16u);
     };
 
     // ---- fragment-read plan ------------------------------------------------------------------------------------
-    int rd_off[3][2];  // [dx][ks]: piece index of (halo row 4*wave, px r+dx, k-step ks) for this lane
+    int rd_off[3][2];  // [dx][ks]: piece index of (halo row RPW*wave, px r+dx, k-step ks) for this lane
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-            rd_off[dx][ks] = (4 * wave) * ROW_PIECES + (r + dx) * 4 + ((2 * ks + h) ^ (((r + dx) >> 2) & 3));
+            rd_off[dx][ks] = (RPW * wave) * ROW_PIECES + (r + dx) * 4 + ((2 * ks + h) ^ (((r + dx) >> 2) & 3));
 
     auto load_group = [&](Frags<CT>& f, const uint4* a, const uint4* wl, int g) {
         const int ks = g / 3, dx = g - ks * 3;
 #pragma unroll
-        for (int row = 0; row < 6; ++row) f.x[row] = a[row * ROW_PIECES + rd_off[dx][ks]];
+        for (int row = 0; row < RPW + 2; ++row) f.x[row] = a[row * ROW_PIECES + rd_off[dx][ks]];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) f.w[dy][ct] = wl[(((dy * 3 + dx) * 2 + ks) * CT + ct) * 64];
     };
 
-    f32x16 acc[4][CT];
+    f32x16 acc[RPW][CT];
     f32x16 bias_v[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(const ConvParams p
         const int y0 = (t / tiles_x) * TILE_H;
         const int x0 = (t % tiles_x) * TILE_W;
 #pragma unroll
-        for (int row = 0; row < 4; ++row)
+        for (int row = 0; row < RPW; ++row)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) acc[row][ct] = bias_v[ct];
 
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(const ConvParams p
             // item n has landed (each wave waits for its own DMAs, then the barrier) and every wave is done reading
             // the stages that are refilled during this item
             if (NA == 3 && n + 1 < nitems)
-                asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // ACT_ITERS: activations(n+1) may stay in flight
+                asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // ACT_ITERS: activations(n+1) may stay in flight
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -278,15 +282,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(const ConvParams p
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                    for (int row = 0; row < 4; ++row) {
+                    for (int row = 0; row < RPW; ++row) {
 #pragma unroll
                         for (int ct = 0; ct < CT; ++ct)
                             if (!(dbg & 1)) acc[row][ct] = Op<T>::mfma(f.w[dy][ct], f.x[row + dy], acc[row][ct]);
-                        if (row & 1) {
-                            FW_SB();
-                            dma_slot(gi * 6 + dy * 2 + (row >> 1));
-                            FW_SB();
-                        }
+                        FW_SB();
+                        dma_slot(gi * 6 + dy * 2 + row);
+                        FW_SB();
                     }
             };
 
@@ -327,8 +329,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(const ConvParams p
         if constexpr (EPI == EPI_IMAGE) {
             const int x = x0 + r;
 #pragma unroll
-            for (int row = 0; row < 4; ++row) {
-                const int y = y0 + 4 * wave + row;
+            for (int row = 0; row < RPW; ++row) {
+                const int y = y0 + RPW * wave + row;
                 if (h == 0 && y < p.img_H && x < p.img_W && y < p.H && x < p.W) {
                     const size_t pix = (size_t)y * p.img_W + x;
                     const float cr = acc[row][0][0], cg = acc[row][0][1], cb = acc[row][0][2];
@@ -352,8 +354,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(const ConvParams p
             //     [tile][wave][row][ct][g][lane][4], one contiguous KiB per wave-instruction, no transposition;
             //     NHWC (op-level API) is the slow general form.
 #pragma unroll
-            for (int row = 0; row < 4; ++row) {
-                const int y = y0 + 4 * wave + row;
+            for (int row = 0; row < RPW; ++row) {
+                const int y = y0 + RPW * wave + row;
                 const int x = x0 + r;
                 const bool inside = y < p.H && x < p.W;
                 const size_t pix = (size_t)y * p.W + x;
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(const ConvParams p
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const size_t nat = ((((((size_t)t * 4 + wave) * 4 + row) * CT + ct) * 4 + g) * 64 + lane) * 4;
+                        const size_t nat = ((((((size_t)t * NWAVES + wave) * RPW + row) * CT + ct) * 4 + g) * 64 + lane) * 4;
                         const size_t lin = pix * (p.f32_cstride ? p.f32_cstride : NC) + p.f32_coff + 32 * ct + 8 * g + 4 * h;
                         const size_t fo = p.f32_native ? nat : lin;
                         const bool fok = p.f32_native || inside;
@@ -389,15 +391,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(const ConvParams p
                     }
             }
             // (2) typed NHWC output: transpose each row through LDS so that one wave-instruction stores whole
-            //     pixels (16 B per lane, contiguous).  Scratch = halo rows 4w+2, 4w+3 of the activation stage just
-            //     consumed: no other wave reads them, and the stage is refilled only after the next barrier.
+            //     pixels (16 B per lane, contiguous).  Scratch = a private 4352-byte slice of the activation stage just
+            //     consumed (every wave has finished reading it after the barrier; it is refilled only after the next
+            //     chunk barrier).
             if (p.out) {
                 constexpr int PSTR = CT == 1 ? 80 : 136;   // bytes per pixel in scratch (padded: conflict-free writes)
-                char* scr = reinterpret_cast<char*>(lds + ((n - 1) % NA) * ACT_REGION + (4 * wave + 2) * ROW_PIECES);
+                __syncthreads();
+                char* scr = reinterpret_cast<char*>(lds + ((n - 1) % NA) * ACT_REGION) + wave * 4352;
                 T* outp = reinterpret_cast<T*>(p.out);
 #pragma unroll
-                for (int row = 0; row < 4; ++row) {
-                    const int y = y0 + 4 * wave + row;
+                for (int row = 0; row < RPW; ++row) {
+                    const int y = y0 + RPW * wave + row;
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(const ConvParams p
 
 #undef FW_SB
 
-static_assert(ACT_ITERS == 10, "the counted s_waitcnt vmcnt(10) in the kernel assumes 10 activation DMAs per wave");
+static_assert(ACT_ITERS == 5, "the counted s_waitcnt vmcnt(5) in the kernel assumes 5 activation DMAs per wave");
 
 // 256 bytes of zeros per device: the DMA source of halo positions outside the image.
 static const void* zero_page() {
@@ -474,7 +478,7 @@ template <typename T>
 static void launch_typed(int cout_tiles, ConvEpilogue epi, const ConvParams& p, hipStream_t stream) {
     const int tiles = ((p.W + TILE_W - 1) / TILE_W) * ((p.H + TILE_H - 1) / TILE_H);
     // persistent workgroups: one per CU (LDS-limited), each walks a contiguous range of tiles
-    dim3 grid(tiles < num_cus() ? tiles : num_cus()), block(256);
+    dim3 grid(tiles < num_cus() ? tiles : num_cus()), block(64 * NWAVES);
     if (cout_tiles == 1 && epi == EPI_STORE)
         hipLaunchKernelGGL((conv3x3_mfma_kernel<T, 1, EPI_STORE>), grid, block, 0, stream, p);
     else if (cout_tiles == 2 && epi == EPI_STORE)
