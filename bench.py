@@ -73,23 +73,31 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
+    # rehearsal of the multi-rank path on a 1-GPU box only: FW_BENCH_FORCE_DEVICE=0 puts every rank on one card
+    dev_ord = int(os.environ.get("FW_BENCH_FORCE_DEVICE", local_rank))
+    torch.cuda.set_device(dev_ord)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo" if "FW_BENCH_FORCE_DEVICE" in os.environ else "nccl")
 
     from framewright_amd import build as fw_build
     if rank == 0:
         fw_build.build()
-    if world > 1:
-        dist.barrier()
+    def barrier():
+        if world > 1:
+            if dist.get_backend() == "nccl":
+                dist.barrier(device_ids=[dev_ord])
+            else:
+                dist.barrier()
+
+    barrier()
     from framewright_amd.realesrgan import RRDBNetEngine
     from framewright_amd.synth import RRDB_MODELS, synthetic_frames, synthetic_rrdbnet_state
 
     num_block, scale = RRDB_MODELS[args.model]
     H, W = args.height, args.width
     sd = synthetic_rrdbnet_state(num_block, scale, seed=1234)
-    eng = RRDBNetEngine(num_block, scale, args.dtype, device_id=local_rank)
+    eng = RRDBNetEngine(num_block, scale, args.dtype, device_id=dev_ord)
     eng.load_state_dict(sd)
 
     # this rank's shard of the clip: frames rank, rank+world, ... (round-robin); a few distinct frames are kept
@@ -105,8 +113,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -115,11 +122,10 @@ def main():
         step(i)
     ev1.record()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    t = torch.tensor([wall], dtype=torch.float64, device="cpu" if "FW_BENCH_FORCE_DEVICE" in os.environ else "cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
@@ -138,6 +144,14 @@ def main():
         fps = world * args.steps / wall_max
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.dtype]
+        # HBM traffic per conv launch from the committed PMC run of this same command (separate rocprofv3 --pmc passes,
+        # gfx950 FETCH_SIZE correction applied) — bench.py cannot collect PMC counters itself.
+        traffic, traffic_note = None, None
+        tf = ROOT / "profiles" / "r01_traffic.json"
+        if tf.exists() and (H, W, args.model) == (1080, 1920, "RealESRGAN_x4plus"):
+            tj = json.loads(tf.read_text())
+            traffic = tj["hbm_bytes_per_launch"]
+            traffic_note = f"profiles/r01_traffic.json ({tj['hbm_tb_per_s']:.2f} TB/s of real HBM traffic while profiled)"
         res = {
             "metric": "frames/sec Real-ESRGAN x4 1080p (RRDBNet-x4plus, 1920x1080 -> 7680x4320)",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -150,7 +164,7 @@ def main():
             "device_ms_per_step": dev_ms / args.steps,
             "whole_path_tflops_per_gpu": flops_frame * args.steps / (dev_ms * 1e-3) / 1e12,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None,
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": "conv3x3_mfma_kernel (all instantiations)",
                          "launches_timed": launches, "avg_launch_ms": conv_ms / max(launches, 1),
                          "avg_launch_gflop": conv_flops / max(launches, 1) / 1e9},
@@ -160,7 +174,7 @@ def main():
         print(json.dumps(res), flush=True)
     eng.close()
     if world > 1:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 

@@ -216,3 +216,22 @@ def test_full_size_properties_1080p_x4(hip_lib):
     torch.cuda.synchronize()
     assert torch.equal(full, full2)
     eng.close()
+
+
+def test_out_of_memory_is_reported_with_the_word_memory(hip_lib, tmp_path, monkeypatch):
+    """restorer.py:1746 retries with a smaller tile when the error text contains "memory"/"vram": a frame whose
+    workspace cannot be allocated must come back as (False, "GPU out of memory ...") — not as a crash."""
+    sd = synthetic_rrdbnet_state(1, 4, seed=1)
+    eng = R.RRDBNetEngine(1, 4, "bf16")
+    eng.load_state_dict(sd)
+    assert eng.workspace_bytes(16384, 16384) > 400e9            # > 288 GB of HBM
+    big = torch.empty((16384, 16384, 3), dtype=torch.uint8, device="cuda")
+    out = torch.empty((8, 8, 3), dtype=torch.uint8, device="cuda")  # never written: the allocation fails first
+    with pytest.raises(_lib.FramewrightOutOfMemory, match="memory"):
+        eng._lib  # noqa: B018
+        _lib.check(eng._lib.fw_rrdbnet_upscale_u8(eng._h, big.data_ptr(), _lib.FW_DEVICE, 16384, 16384, out.data_ptr(),
+                                                  _lib.FW_DEVICE, None, None))
+    # the engine is still usable afterwards
+    small = synthetic_frames(1, 16, 16, seed=1)[0]
+    assert eng.upscale(small).shape == (64, 64, 3)
+    eng.close()

@@ -23,7 +23,8 @@ LIB_PATH = LIB_DIR / "libframewright_hip.so"
 ARCH = "gfx950"
 # frame_ops.hip restates float32 numpy arithmetic bit for bit (a*b + c rounds twice): no FMA contraction there
 PER_FILE_FLAGS = {"frame_ops.hip": ["-ffp-contract=off"]}
-CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+EXTRA = os.environ.get("FW_EXTRA_CXXFLAGS", "").split()
+CXXFLAGS = [*EXTRA, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 
 
 def hipcc() -> str:

@@ -114,7 +114,11 @@ struct Frags {
     uint4 w[3][CT];
 };
 
+#ifdef FW_NO_SB
+#define FW_SB()
+#else
 #define FW_SB() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 template <typename T, int CT, int EPI>
 __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const ConvParams p) {

@@ -139,6 +139,7 @@ struct Error : std::runtime_error {
     do {                                                                                          \
         hipError_t _e = (expr);                                                                   \
         if (_e != hipSuccess) {                                                                   \
+            (void)hipGetLastError(); /* clear the sticky error so the handle stays usable */      \
             int _code = (_e == hipErrorOutOfMemory) ? 2 : 3;                                      \
             throw fw::Error(_code, std::string(_e == hipErrorOutOfMemory ? "GPU out of memory: " : \
                                                                            "HIP error: ") +       \
