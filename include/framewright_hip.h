@@ -141,6 +141,16 @@ int fw_conv3x3_nhwc_ex(int dtype, const void* x, int in_cstride, long in_plane_s
                        int post_act, int f32_cstride, int f32_coff, void* out, int out_cstride, long out_plane_stride,
                        int out_coff, float* out_f32, void* stream);
 
+/* Two chained growth convolutions of a residual dense block in one kernel (aesrgan_face.py:184-187):
+ *   x_a = lrelu(conv_a(x[0 : 32*in_chunks]) + bias_a)            (32 channels) -> out_a
+ *   x_b = lrelu(conv_b(cat(x[0 : 32*in_chunks], x_a)) + bias_b)  (32 channels) -> out_b
+ * packed_weight_a = fw_pack_conv3x3(cout 32, cin 32*in_chunks, 1, in_chunks), packed_weight_b likewise with
+ * in_chunks + 1 (its last chunk multiplies x_a).  out_a / out_b: operand-typed, out_cstride elements per pixel.
+ * The shared input chunks are fetched from HBM once for both convolutions and x_a feeds conv_b from LDS. */
+int fw_conv3x3_pair_nhwc(int dtype, const void* x, int in_cstride, long in_plane_stride, int in_chunks, int height,
+                         int width, const void* packed_weight_a, const float* bias_a, const void* packed_weight_b,
+                         const float* bias_b, void* out_a, void* out_b, int out_cstride, void* stream);
+
 /* -------------------------------------------------------------------------------------------------
  * TAP temporal denoise: NAFNet
  * replaces  basicsr NAFNet construction + load in TAPDenoiser._load_nafnet (processors/tap_denoise.py:335-364),

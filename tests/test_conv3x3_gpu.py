@@ -172,3 +172,31 @@ def test_conv_chunk_planar_layout(hip_lib, dtype):
     ref = _ref(dtype, x, cin, w, b, act=1)
     got = out.permute(1, 2, 0, 3).reshape(H, W, 64).float()
     assert (got - ref).abs().max().item() < (2e-2 if dtype == _lib.FW_DTYPE_BF16 else 3e-3)
+
+
+@pytest.mark.parametrize("dtype", [_lib.FW_DTYPE_BF16, _lib.FW_DTYPE_F16])
+@pytest.mark.parametrize("na,H,W", [(2, 14, 30), (2, 33, 71), (4, 40, 64), (2, 3, 5), (4, 29, 91)])
+def test_conv_pair_fused(hip_lib, dtype, na, H, W):
+    """conv_a + conv_b fused (csrc/conv3x3_pair.hip) vs two torch convs with x_a rounded to the operand type in between,
+    chunk-planar layout, tile borders (14x30 valid outputs per tile) and image borders (zero padding of x_a)."""
+    rng = np.random.default_rng(na * 100 + H)
+    cin = 32 * na
+    x = torch.from_numpy(rng.standard_normal((H, W, cin)).astype(np.float32)).cuda().to(TDT[dtype])
+    planes = x.reshape(H, W, na, 32).permute(2, 0, 1, 3).contiguous()
+    wa = (rng.standard_normal((32, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32)
+    wb = (rng.standard_normal((32, cin + 32, 3, 3)) / np.sqrt(9 * (cin + 32))).astype(np.float32)
+    ba, bb = rng.standard_normal(32).astype(np.float32), rng.standard_normal(32).astype(np.float32)
+    pa, pb = _pack(hip_lib, dtype, wa, 1, na), _pack(hip_lib, dtype, wb, 1, na + 1)
+    ta, tb = torch.from_numpy(ba).cuda(), torch.from_numpy(bb).cuda()
+    oa = torch.full((H, W, 32), 5.0, dtype=TDT[dtype], device="cuda")
+    ob = torch.full((H, W, 32), 5.0, dtype=TDT[dtype], device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(hip_lib.fw_conv3x3_pair_nhwc(dtype, p(planes), 32, H * W * 32, na, H, W, p(pa), p(ta), p(pb), p(tb), p(oa),
+                                            p(ob), 32, None))
+    torch.cuda.synchronize()
+    ref_a = _ref(dtype, x, cin, wa, ba, act=1)
+    xa_t = ref_a.to(TDT[dtype])
+    ref_b = _ref(dtype, torch.cat([x, xa_t], dim=2), cin + 32, wb, bb, act=1)
+    tol = 2e-2 if dtype == _lib.FW_DTYPE_BF16 else 3e-3
+    assert (oa.float() - ref_a).abs().max().item() < tol
+    assert (ob.float() - ref_b).abs().max().item() < 2 * tol

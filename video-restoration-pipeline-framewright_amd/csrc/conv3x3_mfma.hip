@@ -23,102 +23,9 @@
 #include <mutex>
 #include <cstdlib>
 #include "fw_internal.h"
+#include "conv_common.h"
 
 namespace fw {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-
-template <typename T>
-struct Op;
-template <>
-struct Op<__bf16> {
-    static __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
-                                                       0, 0, 0);
-    }
-    static __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
-        bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
-        return __builtin_bit_cast(uint2, v);
-    }
-};
-template <>
-struct Op<_Float16> {
-    static __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0,
-                                                      0, 0);
-    }
-    static __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
-        f16x4 v = {(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};
-        return __builtin_bit_cast(uint2, v);
-    }
-};
-
-constexpr int TILE_H = 16;
-constexpr int TILE_W = 32;
-constexpr int HALO_H = TILE_H + 2;                        // 18
-constexpr int HALO_W = TILE_W + 2;                        // 34
-constexpr int ROW_PIECES = HALO_W * 4;                    // 136 16-byte pieces per halo row
-constexpr int ACT_PIECES = HALO_H * ROW_PIECES;           // 2448 pieces per 32-channel chunk
-constexpr int ACT_INSTR = 40;                            // wave-instructions of 1 KiB per chunk (39 used + 1 pad)
-constexpr int ACT_REGION = ACT_INSTR * 64;                // 2560 pieces = 40 KiB per stage
-constexpr int NWAVES = 8;                                 // 512 threads: two waves per SIMD hide each other's stalls
-constexpr int RPW = TILE_H / NWAVES;                      // output rows per wave (2)
-constexpr int ACT_ITERS = ACT_INSTR / NWAVES;             // 5 per wave, every wave issues all of them
-constexpr int W_FRAGS = 18;                               // 9 taps x 2 k-steps of 16, per cout tile
-
-// LDS image of one activation chunk: [halo row][halo px][4 slots of 16 B]; slot s (= 8 channels) of pixel p is
-// stored at slot s ^ ((p >> 2) & 3).  A fragment read takes, for 16 lanes with distinct p mod 16, the 256-byte
-// bank row positions (p & 3) * 64 + (s ^ ((p >> 2) & 3)) * 16: all 16 distinct -> conflict free.
-// The image is filled by LDS-DMA (global_load_lds_dwordx4): the LDS destination of a wave-instruction is
-// lane-linear, so the swizzle is applied on the per-lane SOURCE address (cdna_hip_programming.md rule 21).
-// Lanes whose halo position is outside the image read a 16-byte zero page instead, so every wave issues the same
-// number of DMA instructions per stage (the counted s_waitcnt vmcnt below relies on it) and zero padding costs
-// nothing.
-
-template <int CT>
-struct Smem {
-    static constexpr int NA = CT == 1 ? 3 : 2;                  // activation stages in flight
-    static constexpr int W_ITERS = (W_FRAGS * CT + NWAVES - 1) / NWAVES;  // weight DMAs per wave per stage (<= 3 or 5)
-    static constexpr int W_REGION = W_FRAGS * CT * 64;          // pieces per weight stage
-    static constexpr int W_BASE = NA * ACT_REGION;
-    static constexpr int TOTAL = NA * ACT_REGION + 2 * W_REGION;  // CT=1: 156 KiB; CT=2: 152 KiB
-};
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-// One global_load_lds_dwordx4: every lane copies 16 bytes from its own global address to LDS[lds_dst + 16 * lane];
-// lds_dst is wave-uniform.  Inline asm so that hipcc does not count these loads: with the builtin it drains them
-// (s_waitcnt vmcnt(0)) before the first ds_read of the chunk being computed, which serialises the pipeline
-// (cdna_hip_programming.md §5 "Three .s-level traps" (b)).  The matching waits are the explicit counted vmcnt at
-// the top of the chunk loop.  M0 is written inside the statement; nothing else in this kernel uses M0.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-    asm volatile(
-        "s_mov_b32 m0, %1\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %0, off"
-        :
-        : "v"(gsrc), "s"(lds_dst)
-        : "memory");
-}
-
-// Fragments of one (k-step, dx) group: the wave's RPW+2 halo rows at column offset dx and the 3 (dy) weight
-// fragments per cout tile -> 3*RPW*CT MFMAs.
-template <int CT>
-struct Frags {
-    uint4 x[RPW + 2];
-    uint4 w[3][CT];
-};
-
-#ifdef FW_NO_SB
-#define FW_SB()
-#else
-#define FW_SB() __builtin_amdgcn_sched_barrier(0)
-#endif
 
 template <typename T, int CT, int EPI>
 __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const ConvParams p) {
@@ -466,6 +373,8 @@ size_t f32_native_elems(int H, int W, int cout_tiles) {
     const size_t tiles = (size_t)((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
     return tiles * (TILE_H * TILE_W) * 32 * cout_tiles;
 }
+
+const void* conv_zero_page() { return zero_page(); }
 
 static int num_cus() {
     static int n = [] {

@@ -1,0 +1,313 @@
+// Two chained 3x3 convolutions of a residual dense block in ONE kernel:  x_a = lrelu(conv_a([x..]))  and
+// x_b = lrelu(conv_b([x.., x_a])) — conv1+conv2 and conv3+conv4 of reference
+// src/framewright/processors/aesrgan_face.py:184-187.
+//
+// Why: the unfused path is HBM-bound and conv_b re-reads everything conv_a just read.  Here every input
+// chunk is staged ONCE and feeds BOTH convolutions while it sits in LDS (two accumulator sets, like a 64-output-channel
+// conv whose second half belongs to conv_b); after the last shared chunk x_a is finished, written to LDS in the same
+// swizzled halo-tile format the LDS-DMA produces, and one more K-step adds W_b[last chunk] * x_a.
+//
+// Geometry: both convs are evaluated on the same 16x32 "compute region" with the standard 18x34 halo tile.
+// conv_b's zero-padded stencil over x_a is only valid one pixel inside the region, so a tile delivers 14x30 pixels
+// (neighbouring tiles recompute the 1-pixel ring: +22 % MFMA work on these four convs, +12 % on the block, for about
+// half of their HBM reads).  x_a outside the image is zero (= conv_b's zero padding).  The x_a tile doubles as the
+// transpose buffer for the coalesced 16-B global stores of x_a and x_b.
+#include <mutex>
+#include <type_traits>
+#include "fw_internal.h"
+#include "conv_common.h"
+
+namespace fw {
+
+constexpr int PAIR_TH = TILE_H - 2;  // 14 valid rows per tile
+constexpr int PAIR_TW = TILE_W - 2;  // 30 valid pixels per tile row
+
+struct PairSmem {
+    static constexpr int NA = 2;                          // activation stages (the x_a tile borrows the idle one)
+    static constexpr int W_REGION = 2 * W_FRAGS * 64;     // weight chunk of conv_a (18 fragments) + conv_b (18)
+    static constexpr int W_BASE = NA * ACT_REGION;
+    static constexpr int W_ITERS = (2 * W_FRAGS + NWAVES - 1) / NWAVES;  // 5
+    static constexpr int TOTAL = W_BASE + 2 * W_REGION;   // 152 KiB
+};
+
+struct PairFrags {
+    uint4 x[RPW + 2];
+    uint4 wa[3];
+    uint4 wb[3];
+};
+
+template <typename T>
+__global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const ConvPairParams p) {
+    using SM = PairSmem;
+    __shared__ __attribute__((aligned(16))) uint4 lds[SM::TOTAL];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int r = lane & 31;
+    const int h = lane >> 5;
+
+    const int NB = gridDim.x;
+    const int xcd = blockIdx.x & 7;
+    const int qn = NB >> 3, rn = NB & 7;
+    const int lb = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blockIdx.x >> 3);
+    const int tiles_x = (p.W + PAIR_TW - 1) / PAIR_TW;
+    const int ntiles = tiles_x * ((p.H + PAIR_TH - 1) / PAIR_TH);
+    const int t_lo = (int)((long)lb * ntiles / NB);
+    const int t_hi = (int)((long)(lb + 1) * ntiles / NB);
+    if (t_lo >= t_hi) return;
+    const int na = p.na;             // input chunks shared by both convs
+    const int ipt = na + 1;          // items per tile: na shared chunks (both convs), then conv_b's x_a chunk
+    const int nitems = (t_hi - t_lo) * ipt;
+
+    // ---- per-lane DMA plan (as in conv3x3_mfma.hip; the compute region plays the role of the tile) ----------------------
+    int rel[ACT_ITERS];
+    int rp[ACT_ITERS];
+#pragma unroll
+    for (int i = 0; i < ACT_ITERS; ++i) {
+        const int idx = (wave + NWAVES * i) * 64 + lane;
+        const int row = idx / ROW_PIECES;
+        const int rm = idx - row * ROW_PIECES;
+        const int px = rm >> 2;
+        const int s = (rm & 3) ^ ((px >> 2) & 3);
+        rel[i] = ((row - 1) * p.W + (px - 1)) * p.in_cstride + s * 8;
+        rp[i] = (idx < ACT_PIECES) ? ((row << 8) | px) : -1;
+    }
+    const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)lds;
+    const T* in = reinterpret_cast<const T*>(p.in);
+    const char* wa_b = reinterpret_cast<const char*>(p.wpk_a) + lane * 16;
+    const char* wb_b = reinterpret_cast<const char*>(p.wpk_b) + lane * 16;
+    const unsigned chunk_bytes = (unsigned)(p.in_pstride * 2);
+
+    // compute-region origin of tile t (may be -1: the region starts one pixel outside the tile's valid outputs)
+    auto origin = [&](int t, int* oy, int* ox) {
+        *oy = (t / tiles_x) * PAIR_TH - 1;
+        *ox = (t % tiles_x) * PAIR_TW - 1;
+    };
+
+    // activation fetch stream: per tile the chunks 0..na-1, each fetched once
+    const char* src[ACT_ITERS];
+    unsigned inc[ACT_ITERS];
+    int f_t = t_lo, f_c = 0;
+    auto plan_tile = [&]() {
+        int oy, ox;
+        origin(f_t, &oy, &ox);
+        const T* base = in + ((long)oy * p.W + ox) * p.in_cstride;
+#pragma unroll
+        for (int i = 0; i < ACT_ITERS; ++i) {
+            const int gy = oy - 1 + (rp[i] >> 8);
+            const int gx = ox - 1 + (rp[i] & 255);
+            const bool ok = rp[i] >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            src[i] = ok ? reinterpret_cast<const char*>(base + rel[i]) : reinterpret_cast<const char*>(p.zeros);
+            inc[i] = ok ? chunk_bytes : 0u;
+        }
+    };
+    auto issue_act_one = [&](int i, int stage) {
+        if (i == 0 && f_c == 0) plan_tile();
+        glds16(src[i], lds_base + (unsigned)(stage * ACT_REGION + (wave + NWAVES * i) * 64) * 16u);
+        src[i] += inc[i];
+        if (i == ACT_ITERS - 1 && ++f_c == na) {
+            f_c = 0;
+            ++f_t;
+        }
+    };
+    // weights of item j of a tile -> weight stage ws: fragments [0,18) = conv_a chunk j, [18,36) = conv_b chunk j;
+    // the last item (j == na) only has conv_b's chunk
+    auto issue_w_one = [&](int i, int j, int ws) {
+        const int f = wave + NWAVES * i;
+        if (f < 2 * W_FRAGS && (j < na || f >= W_FRAGS)) {
+            const char* w = f < W_FRAGS ? wa_b + (size_t)j * (W_FRAGS * 1024) + f * 1024
+                                        : wb_b + (size_t)j * (W_FRAGS * 1024) + (f - W_FRAGS) * 1024;
+            glds16(w, lds_base + (unsigned)(SM::W_BASE + ws * SM::W_REGION + f * 64) * 16u);
+        }
+    };
+
+    int rd_off[3][2];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            rd_off[dx][ks] = (RPW * wave) * ROW_PIECES + (r + dx) * 4 + ((2 * ks + h) ^ (((r + dx) >> 2) & 3));
+
+    auto load_group = [&](PairFrags& f, const uint4* a, const uint4* wl, int g, bool both) {
+        const int ks = g / 3, dx = g - ks * 3;
+#pragma unroll
+        for (int row = 0; row < RPW + 2; ++row) f.x[row] = a[row * ROW_PIECES + rd_off[dx][ks]];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            if (both) f.wa[dy] = wl[((dy * 3 + dx) * 2 + ks) * 64];
+            f.wb[dy] = wl[(W_FRAGS + (dy * 3 + dx) * 2 + ks) * 64];
+        }
+    };
+
+    f32x16 acc_a[RPW], acc_b[RPW];
+
+    // acc (+bias already inside) -> LeakyReLU -> typed -> tile in LDS at `xa` (halo format, zero outside the image when
+    // `zero_outside`), then the wave copies its own rows' valid interior to the global plane with 16-B/lane stores.
+    auto emit = [&](const f32x16* acc, uint4* xa, int oy, int ox, T* plane, bool zero_outside) {
+#pragma unroll
+        for (int row = 0; row < RPW; ++row) {
+            const int cr = RPW * wave + row;  // row inside the compute region
+            const int gy = oy + cr, gx = ox + r;
+            const bool inside = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = acc[row][4 * g + j];
+                    o[j] = (zero_outside && !inside) ? 0.f : fmaxf(v, 0.2f * v);
+                }
+                char* dst = reinterpret_cast<char*>(xa + ((cr + 1) * HALO_W + (r + 1)) * 4 + (g ^ (((r + 1) >> 2) & 3))) + 8 * h;
+                *reinterpret_cast<uint2*>(dst) = Op<T>::pack4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        // copy-out: 64 lanes = 16 pixels x 4 physical slots; logical slot = physical ^ swizzle(px)
+#pragma unroll
+        for (int row = 0; row < RPW; ++row) {
+            const int cr = RPW * wave + row;
+            const int gy = oy + cr;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int cp = it * 16 + (lane >> 2);  // pixel inside the compute region
+                const int k = lane & 3;
+                const int hp = cp + 1;                  // halo-tile pixel
+                const uint4 v = xa[((cr + 1) * HALO_W + hp) * 4 + k];
+                const int s = k ^ ((hp >> 2) & 3);
+                const int gx = ox + cp;
+                if (cr >= 1 && cr <= PAIR_TH && cp >= 1 && cp <= PAIR_TW && (unsigned)gy < (unsigned)p.H &&
+                    (unsigned)gx < (unsigned)p.W)
+                    *reinterpret_cast<uint4*>(plane + ((size_t)gy * p.W + gx) * p.out_cstride + s * 8) = v;
+            }
+        }
+    };
+
+    // ---- pipeline: one item of look-ahead.  Activation stage of DMA item q (q-th fetched chunk) = q & 1; the x_a item of a
+    //      tile uses the stage of the tile's last shared chunk (free again after a barrier), while the other stage already
+    //      receives the next tile's first chunk. -----------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < SM::W_ITERS; ++i) issue_w_one(i, 0, 0);
+#pragma unroll
+    for (int i = 0; i < ACT_ITERS; ++i) issue_act_one(i, 0);
+
+    int n = 0;   // global item counter (weight stage = n & 1)
+    int q = 0;   // DMA'd chunks consumed so far
+    for (int t = t_lo; t < t_hi; ++t) {
+        int oy, ox;
+        origin(t, &oy, &ox);
+        // accumulators start at the bias (re-read per tile: 128 B from L1/L2, cheaper than 32 live registers)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float ba = p.bias_a[(i & 3) + 8 * (i >> 2) + 4 * h];
+            const float bb = p.bias_b[(i & 3) + 8 * (i >> 2) + 4 * h];
+#pragma unroll
+            for (int row = 0; row < RPW; ++row) {
+                acc_a[row][i] = ba;
+                acc_b[row][i] = bb;
+            }
+        }
+        // one pipeline item; BOTH = shared input chunk (feeds conv_a and conv_b), !BOTH = conv_b's x_a chunk
+        auto run_item = [&](int j, auto both_tag) {
+            constexpr bool BOTH = decltype(both_tag)::value;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const bool more = n + 1 < nitems;
+            const int jn = (j + 1 == ipt) ? 0 : j + 1;  // next item's position in its tile
+            // next DMA'd chunk: item j+1 if it is a shared chunk; during the LAST shared chunk the next tile's first
+            // chunk (the x_a item needs no DMA); during the x_a item nothing (both stages are occupied)
+#ifdef FW_PAIR_NO_ACT_DMA   // timing ablation only: compute on stale LDS contents
+            const bool fetch = false;
+#else
+            const bool fetch = BOTH && more && (j + 1 < na || t + 1 < t_hi);
+#endif
+            const int fetch_stage = (q + 1) & 1;
+            auto dma_slot = [&](int d) {
+                if (d < SM::W_ITERS) {
+                    if (more) issue_w_one(d, jn, (n + 1) & 1);
+                } else if (d - SM::W_ITERS < ACT_ITERS) {
+                    if (fetch) issue_act_one(d - SM::W_ITERS, fetch_stage);
+                }
+            };
+            // stage of this item: shared chunk -> q & 1; x_a item -> the stage of the last shared chunk, (q - 1) & 1
+            const uint4* a = lds + ((BOTH ? q : q - 1) & 1) * ACT_REGION;
+            const uint4* wl = lds + SM::W_BASE + (n & 1) * SM::W_REGION + lane;
+            auto mfma_group = [&](const PairFrags& f, int gi) {
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int row = 0; row < RPW; ++row) {
+                        if constexpr (BOTH) acc_a[row] = Op<T>::mfma(f.wa[dy], f.x[row + dy], acc_a[row]);
+                        acc_b[row] = Op<T>::mfma(f.wb[dy], f.x[row + dy], acc_b[row]);
+                        FW_SB();
+                        dma_slot(gi * 6 + dy * 2 + row);
+                        FW_SB();
+                    }
+            };
+            PairFrags fa, fb;
+            load_group(fa, a, wl, 0, BOTH);
+            FW_SB();
+            load_group(fb, a, wl, 1, BOTH);
+            FW_SB();
+            mfma_group(fa, 0);
+            FW_SB();
+            load_group(fa, a, wl, 2, BOTH);
+            FW_SB();
+            mfma_group(fb, 1);
+            FW_SB();
+            load_group(fb, a, wl, 3, BOTH);
+            FW_SB();
+            mfma_group(fa, 2);
+            FW_SB();
+            load_group(fa, a, wl, 4, BOTH);
+            FW_SB();
+            mfma_group(fb, 3);
+            FW_SB();
+            load_group(fb, a, wl, 5, BOTH);
+            FW_SB();
+            mfma_group(fa, 4);
+            FW_SB();
+            mfma_group(fb, 5);
+            FW_SB();
+            if (BOTH) ++q;
+            ++n;
+        };
+        for (int j = 0; j < na; ++j) run_item(j, std::true_type{});
+        // conv_a done.  Every wave must be finished with the last chunk's stage before it becomes the x_a tile.
+        __syncthreads();
+        emit(acc_a, lds + ((q - 1) & 1) * ACT_REGION, oy, ox, reinterpret_cast<T*>(p.out_a), true);
+        run_item(na, std::false_type{});
+        // conv_b done: every wave has finished reading the x_a tile before it is reused as the store-transpose buffer
+        __syncthreads();
+        emit(acc_b, lds + ((q - 1) & 1) * ACT_REGION, oy, ox, reinterpret_cast<T*>(p.out_b), false);
+    }
+}
+
+static int pair_num_cus() {
+    static int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        return v;
+    }();
+    return n;
+}
+
+void launch_conv3x3_pair(DType dt, const ConvPairParams& p_in, hipStream_t stream) {
+    ConvPairParams p = p_in;
+    if (p.H <= 0 || p.W <= 0 || p.na < 1 || p.na > 8) throw Error(1, "conv3x3_pair: bad problem");
+    if (p.in_cstride < 32 || (p.in_cstride & 7) || p.in_pstride < 32 || (p.in_pstride & 7) || (p.out_cstride & 7) ||
+        p.out_cstride < 32)
+        throw Error(1, "conv3x3_pair: bad strides");
+    if (!p.in || !p.wpk_a || !p.wpk_b || !p.bias_a || !p.bias_b || !p.out_a || !p.out_b) throw Error(1, "conv3x3_pair: NULL");
+    p.zeros = conv_zero_page();
+    const int tiles = ((p.W + PAIR_TW - 1) / PAIR_TW) * ((p.H + PAIR_TH - 1) / PAIR_TH);
+    dim3 grid(tiles < pair_num_cus() ? tiles : pair_num_cus()), block(64 * NWAVES);
+    if (dt == DT_BF16)
+        hipLaunchKernelGGL((conv3x3_pair_kernel<__bf16>), grid, block, 0, stream, p);
+    else
+        hipLaunchKernelGGL((conv3x3_pair_kernel<_Float16>), grid, block, 0, stream, p);
+    FW_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace fw

@@ -56,6 +56,26 @@ struct ConvParams {
 // [tile][wave][row][ct][g][lane][4] over the padded 16x32 tile grid.
 size_t f32_native_elems(int H, int W, int cout_tiles);
 
+// Two chained 32-output-channel convs in one kernel (conv3x3_pair.hip): x_a = lrelu(conv_a(in[0:32*na])),
+// x_b = lrelu(conv_b(cat(in[0:32*na], x_a))).
+struct ConvPairParams {
+    const void* in;        // operand-typed, chunk c / pixel (y,x) at c*in_pstride + (y*W + x)*in_cstride
+    int in_cstride;
+    long in_pstride;
+    int na;                // 32-channel input chunks of conv_a (conv_b contracts na + 1 chunks)
+    int H, W;
+    const void* wpk_a;     // pack_conv3x3_weights(cout 32, cin 32*na)
+    const float* bias_a;   // [32]
+    const void* wpk_b;     // pack_conv3x3_weights(cout 32, cin 32*(na+1)); the last chunk multiplies x_a
+    const float* bias_b;
+    void* out_a;           // typed plane [H][W][out_cstride], 32 channels written
+    void* out_b;
+    int out_cstride;
+    const void* zeros;     // set by launch_conv3x3_pair
+};
+void launch_conv3x3_pair(DType dt, const ConvPairParams& p, hipStream_t stream);
+const void* conv_zero_page();  // 256 B of zeros on the current device
+
 // Launches the kernel; cout_tiles in {1,2} (32 or 64 output channels).
 void launch_conv3x3(DType dt, int cout_tiles, ConvEpilogue epi, const ConvParams& p, hipStream_t stream);
 

@@ -12,6 +12,7 @@
 #include <vector>
 #include <memory>
 #include <cstdio>
+#include <cstdlib>
 #include "fw_internal.h"
 #include "../../include/framewright_hip.h"
 
@@ -49,6 +50,7 @@ struct fw_rrdbnet {
     ConvLayer conv_first, conv_body, conv_up1, conv_up2, conv_hr, conv_last;
     std::vector<ConvLayer> body;  // [num_block][3][5]
     Workspace ws;
+    bool fuse_pairs = true;  // conv1+conv2 / conv3+conv4 in one kernel (FW_RRDB_FUSE_PAIRS=0 disables, for A/B runs)
     // profiling
     bool profile = false;
     std::vector<hipEvent_t> ev_pool;
@@ -189,6 +191,23 @@ void run_conv(fw_rrdbnet* n, const ConvLayer& l, ConvEpilogue epi, ConvParams p,
     }
 }
 
+void run_pair(fw_rrdbnet* n, const ConvLayer& a, const ConvLayer& b, const ConvPairParams& q, hipStream_t st) {
+    if (n->profile) {
+        if (n->ev_used + 2 > n->ev_pool.size()) {
+            size_t old = n->ev_pool.size();
+            n->ev_pool.resize(old + 1024);
+            for (size_t i = old; i < n->ev_pool.size(); ++i) FW_HIP_CHECK(hipEventCreate(&n->ev_pool[i]));
+        }
+        FW_HIP_CHECK(hipEventRecord(n->ev_pool[n->ev_used++], st));
+        launch_conv3x3_pair(n->dt, q, st);
+        FW_HIP_CHECK(hipEventRecord(n->ev_pool[n->ev_used++], st));
+        n->prof_flops += conv_flops(a, (size_t)q.H * q.W) + conv_flops(b, (size_t)q.H * q.W);  // algorithmic, no recompute
+        n->prof_stream = st;
+    } else {
+        launch_conv3x3_pair(n->dt, q, st);
+    }
+}
+
 void forward(fw_rrdbnet* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, float* d_rgb, hipStream_t st) {
     int Ht, Wt;
     trunk_size(n, H, W, &Ht, &Wt);
@@ -234,13 +253,34 @@ void forward(fw_rrdbnet* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, f
         const float* Rin = (b == 0) ? F : R;
         for (int k = 0; k < 3; ++k) {
             const ConvLayer* L = &n->body[((size_t)b * 3 + k) * 5];
-            // conv1..conv4: growth channels, LeakyReLU(0.2), written into the next slice    (:184-187)
-            for (int c = 0; c < 4; ++c) {
-                ConvParams p = base;
-                p.in = cat[cur];
-                p.out = plane(cat[cur], 2 + c, PL);
-                p.act = 1;
-                run_conv(n, L[c], EPI_STORE, p, st);
+            // conv1..conv4: growth channels, LeakyReLU(0.2), written into the next plane    (:184-187);
+            // fused in pairs (conv1+conv2, conv3+conv4): the shared input chunks leave HBM once per pair
+            if (n->fuse_pairs) {
+                for (int c = 0; c < 4; c += 2) {
+                    ConvPairParams q{};
+                    q.in = cat[cur];
+                    q.in_cstride = 32;
+                    q.in_pstride = PL;
+                    q.na = 2 + c;
+                    q.H = Ht;
+                    q.W = Wt;
+                    q.wpk_a = L[c].d_w;
+                    q.bias_a = L[c].d_b;
+                    q.wpk_b = L[c + 1].d_w;
+                    q.bias_b = L[c + 1].d_b;
+                    q.out_a = plane(cat[cur], 2 + c, PL);
+                    q.out_b = plane(cat[cur], 3 + c, PL);
+                    q.out_cstride = 32;
+                    run_pair(n, L[c], L[c + 1], q, st);
+                }
+            } else {
+                for (int c = 0; c < 4; ++c) {
+                    ConvParams p = base;
+                    p.in = cat[cur];
+                    p.out = plane(cat[cur], 2 + c, PL);
+                    p.act = 1;
+                    run_conv(n, L[c], EPI_STORE, p, st);
+                }
             }
             // conv5 + residual(s): x5*0.2 + x  (:188-189); after rdb3 additionally *0.2 + rrdb_in (:204)
             ConvParams p = base;
@@ -350,6 +390,7 @@ int fw_rrdbnet_create(int device_id, int num_block, int scale, int dtype, fw_rrd
         n->scale = scale;
         n->dt = (DType)dtype;
         n->body.resize((size_t)num_block * 15);
+        if (const char* e = getenv("FW_RRDB_FUSE_PAIRS")) n->fuse_pairs = atoi(e) != 0;
         *out = n.release();
     });
 }
@@ -524,6 +565,30 @@ int fw_conv3x3_nhwc(int dtype, const void* x, int in_cstride, long in_plane_stri
     return fw_conv3x3_nhwc_ex(dtype, x, in_cstride, in_plane_stride, cin_chunks, H, W, packed_weight, bias, cout_tiles,
                               act_lrelu, upsample2x, res1, s1, res2, s2, nullptr, 0, 0, 0, out, out_cstride,
                               out_plane_stride, out_coff, out_f32, stream);
+}
+
+int fw_conv3x3_pair_nhwc(int dtype, const void* x, int in_cstride, long in_plane_stride, int in_chunks, int H, int W,
+                         const void* packed_weight_a, const float* bias_a, const void* packed_weight_b, const float* bias_b,
+                         void* out_a, void* out_b, int out_cstride, void* stream) {
+    if (dtype != FW_DTYPE_BF16 && dtype != FW_DTYPE_F16) return fail(FW_ERR_INVALID, "fw_conv3x3_pair_nhwc: bad dtype");
+    return guarded([&] {
+        ConvPairParams q{};
+        q.in = x;
+        q.in_cstride = in_cstride;
+        q.in_pstride = in_plane_stride > 0 ? in_plane_stride : 32;
+        q.na = in_chunks;
+        q.H = H;
+        q.W = W;
+        q.wpk_a = packed_weight_a;
+        q.bias_a = bias_a;
+        q.wpk_b = packed_weight_b;
+        q.bias_b = bias_b;
+        q.out_a = out_a;
+        q.out_b = out_b;
+        q.out_cstride = out_cstride;
+        if (q.in_pstride == 32 && in_cstride < 32 * in_chunks) throw Error(FW_ERR_INVALID, "fw_conv3x3_pair_nhwc: input too narrow");
+        launch_conv3x3_pair((DType)dtype, q, (hipStream_t)stream);
+    });
 }
 
 int fw_conv3x3_nhwc_ex(int dtype, const void* x, int in_cstride, long in_plane_stride, int cin_chunks, int H, int W,
