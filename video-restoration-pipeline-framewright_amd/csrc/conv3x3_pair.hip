@@ -19,6 +19,25 @@
 
 namespace fw {
 
+// timing ablations: build with -DFW_PAIR_DBG=<bits> (1 no activation DMA, 2 no weight DMA, 4 no emit, 8 no MFMA)
+#ifndef FW_PAIR_DBG
+#define FW_PAIR_DBG 0
+#endif
+
+// phase stamps (diagnostic build -DFW_PAIR_STAMP only): wave 0 of every block accumulates s_memtime deltas per phase
+#ifdef FW_PAIR_STAMP
+#define FW_STAMP(slot)                                                   \
+    do {                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                               \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();      \
+        __builtin_amdgcn_sched_barrier(0);                               \
+        stamp_acc[slot] += t_ - stamp_last;                              \
+        stamp_last = t_;                                                 \
+    } while (0)
+#else
+#define FW_STAMP(slot) do { } while (0)
+#endif
+
 constexpr int PAIR_TH = TILE_H - 2;  // 14 valid rows per tile
 constexpr int PAIR_TW = TILE_W - 2;  // 30 valid pixels per tile row
 
@@ -46,6 +65,11 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
     const int lane = tid & 63;
     const int r = lane & 31;
     const int h = lane >> 5;
+#ifdef FW_PAIR_STAMP
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long stamp_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     const int NB = gridDim.x;
     const int xcd = blockIdx.x & 7;
@@ -209,21 +233,20 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
         // one pipeline item; BOTH = shared input chunk (feeds conv_a and conv_b), !BOTH = conv_b's x_a chunk
         auto run_item = [&](int j, auto both_tag) {
             constexpr bool BOTH = decltype(both_tag)::value;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            FW_STAMP(BOTH ? 1 : 2);   // previous phase ends (compute of the previous item / emit)
+            if (!(FW_PAIR_DBG & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FW_STAMP(5);              // waiting for this wave's own DMAs
+            if (!(FW_PAIR_DBG & 16)) __syncthreads();
+            FW_STAMP(0);              // barrier
             const bool more = n + 1 < nitems;
             const int jn = (j + 1 == ipt) ? 0 : j + 1;  // next item's position in its tile
             // next DMA'd chunk: item j+1 if it is a shared chunk; during the LAST shared chunk the next tile's first
             // chunk (the x_a item needs no DMA); during the x_a item nothing (both stages are occupied)
-#ifdef FW_PAIR_NO_ACT_DMA   // timing ablation only: compute on stale LDS contents
-            const bool fetch = false;
-#else
-            const bool fetch = BOTH && more && (j + 1 < na || t + 1 < t_hi);
-#endif
+            const bool fetch = !(FW_PAIR_DBG & 1) && BOTH && more && (j + 1 < na || t + 1 < t_hi);
             const int fetch_stage = (q + 1) & 1;
             auto dma_slot = [&](int d) {
                 if (d < SM::W_ITERS) {
-                    if (more) issue_w_one(d, jn, (n + 1) & 1);
+                    if (more && !(FW_PAIR_DBG & 2)) issue_w_one(d, jn, (n + 1) & 1);
                 } else if (d - SM::W_ITERS < ACT_ITERS) {
                     if (fetch) issue_act_one(d - SM::W_ITERS, fetch_stage);
                 }
@@ -236,8 +259,10 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                     for (int row = 0; row < RPW; ++row) {
-                        if constexpr (BOTH) acc_a[row] = Op<T>::mfma(f.wa[dy], f.x[row + dy], acc_a[row]);
-                        acc_b[row] = Op<T>::mfma(f.wb[dy], f.x[row + dy], acc_b[row]);
+                        if constexpr (!(FW_PAIR_DBG & 8)) {
+                            if constexpr (BOTH) acc_a[row] = Op<T>::mfma(f.wa[dy], f.x[row + dy], acc_a[row]);
+                            acc_b[row] = Op<T>::mfma(f.wb[dy], f.x[row + dy], acc_b[row]);
+                        }
                         FW_SB();
                         dma_slot(gi * 6 + dy * 2 + row);
                         FW_SB();
@@ -271,16 +296,45 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
             if (BOTH) ++q;
             ++n;
         };
+        FW_STAMP(4);  // tile setup (bias -> accumulators)
         for (int j = 0; j < na; ++j) run_item(j, std::true_type{});
+        FW_STAMP(1);
         // conv_a done.  Every wave must be finished with the last chunk's stage before it becomes the x_a tile.
         __syncthreads();
-        emit(acc_a, lds + ((q - 1) & 1) * ACT_REGION, oy, ox, reinterpret_cast<T*>(p.out_a), true);
+        FW_STAMP(0);
+        if (!(FW_PAIR_DBG & 4)) emit(acc_a, lds + ((q - 1) & 1) * ACT_REGION, oy, ox, reinterpret_cast<T*>(p.out_a), true);
+        FW_STAMP(3);  // emit of x_a
         run_item(na, std::false_type{});
+        FW_STAMP(2);  // x_a item compute
         // conv_b done: every wave has finished reading the x_a tile before it is reused as the store-transpose buffer
         __syncthreads();
-        emit(acc_b, lds + ((q - 1) & 1) * ACT_REGION, oy, ox, reinterpret_cast<T*>(p.out_b), false);
+        FW_STAMP(0);
+        if (!(FW_PAIR_DBG & 4)) emit(acc_b, lds + ((q - 1) & 1) * ACT_REGION, oy, ox, reinterpret_cast<T*>(p.out_b), false);
+        FW_STAMP(3);
     }
+#ifdef FW_PAIR_STAMP
+    // slot 7: wall time of the wave in 100 MHz ticks -> in-kernel clock = sum(slots 0..5) / slot 7 * 100 MHz
+    stamp_acc[7] = __builtin_amdgcn_s_memrealtime() - stamp_rt0;
+    if (lane == 0 && p.stamps)
+        for (int k = 0; k < 8; ++k) atomicAdd(p.stamps + wave * 8 + k, stamp_acc[k]);
+#endif
 }
+
+#ifdef FW_PAIR_STAMP
+static unsigned long long* pair_stamp_buffer() {
+    static unsigned long long* buf = nullptr;
+    if (!buf) {
+        FW_HIP_CHECK(hipMalloc((void**)&buf, 512));
+        FW_HIP_CHECK(hipMemset(buf, 0, 512));
+    }
+    return buf;
+}
+extern "C" int fw_debug_pair_stamps(unsigned long long* out) {
+    if (hipMemcpy(out, pair_stamp_buffer(), 512, hipMemcpyDeviceToHost) != hipSuccess) return 3;
+    (void)hipMemset(pair_stamp_buffer(), 0, 512);
+    return 0;
+}
+#endif
 
 static int pair_num_cus() {
     static int n = [] {
@@ -301,6 +355,9 @@ void launch_conv3x3_pair(DType dt, const ConvPairParams& p_in, hipStream_t strea
         throw Error(1, "conv3x3_pair: bad strides");
     if (!p.in || !p.wpk_a || !p.wpk_b || !p.bias_a || !p.bias_b || !p.out_a || !p.out_b) throw Error(1, "conv3x3_pair: NULL");
     p.zeros = conv_zero_page();
+#ifdef FW_PAIR_STAMP
+    p.stamps = pair_stamp_buffer();
+#endif
     const int tiles = ((p.W + PAIR_TW - 1) / PAIR_TW) * ((p.H + PAIR_TH - 1) / PAIR_TH);
     dim3 grid(tiles < pair_num_cus() ? tiles : pair_num_cus()), block(64 * NWAVES);
     if (dt == DT_BF16)

@@ -72,6 +72,7 @@ struct ConvPairParams {
     void* out_b;
     int out_cstride;
     const void* zeros;     // set by launch_conv3x3_pair
+    unsigned long long* stamps;  // diagnostic builds only (-DFW_PAIR_STAMP)
 };
 void launch_conv3x3_pair(DType dt, const ConvPairParams& p, hipStream_t stream);
 const void* conv_zero_page();  // 256 B of zeros on the current device
