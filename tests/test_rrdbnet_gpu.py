@@ -135,6 +135,33 @@ def test_kernel_vs_operand_rounded_oracle(hip_lib, dtype):
     assert np.abs(rgb - want).max() < 2e-4
 
 
+@pytest.mark.parametrize("dtype,tol_max,tol_mean", [("f16", 5e-4, 1e-4), ("bf16", 4e-3, 8e-4)])
+@pytest.mark.parametrize("nb,scale,H,W", [(23, 4, 40, 56), (2, 2, 37, 45)])
+def test_split_trunk_matches_fp32_trunk(hip_lib, monkeypatch, dtype, tol_max, tol_mean, nb, scale, H, W):
+    """The residual trunk kept as typed hi + typed lo planes (the default) against the fp32 trunk it replaces
+    (FW_RRDB_SPLIT_TRUNK=0).  hi + lo carries 16 (bf16) / 22 (f16) mantissa bits, so the trunks agree to ~1e-6; what
+    the outputs show is operands whose rounding to the operand type flips, amplified through 69 dense blocks: a
+    fraction of the operand-rounding error of the path itself.  So the second check is against the fp32 oracle: the
+    split trunk must be as close to it as the fp32 trunk is.  Edge tiles, ragged sizes and the in-place update of the
+    RRDB input by rdb3 are all exercised."""
+    sd = synthetic_rrdbnet_state(nb, scale, seed=5)
+    frame = synthetic_frames(1, H, W, seed=6)[0]
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FW_RRDB_SPLIT_TRUNK", mode)
+        eng = R.RRDBNetEngine(nb, scale, dtype)
+        eng.load_state_dict(sd)
+        outs.append(_gpu_rgb_f32(eng, frame))
+        eng.close()
+    (rgb_s, u8_s), (rgb_f, u8_f) = outs
+    d = np.abs(rgb_s - rgb_f)
+    assert d.max() < tol_max and d.mean() < tol_mean, (d.max(), d.mean())
+    assert np.abs(u8_s.astype(int) - u8_f.astype(int)).max() <= 1
+    want = _oracle_rgb_f32(sd, frame, nb, scale)
+    e_s, e_f = np.abs(rgb_s - want).mean(), np.abs(rgb_f - want).mean()
+    assert e_s < 1.25 * e_f + 1e-6, (e_s, e_f)
+
+
 def test_upscale_host_buffers_and_determinism(hip_lib):
     sd = synthetic_rrdbnet_state(2, 4, seed=5)
     frame = synthetic_frames(1, 30, 50, seed=3)[0]

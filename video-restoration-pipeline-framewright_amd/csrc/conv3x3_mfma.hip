@@ -38,6 +38,8 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
     const int lane = tid & 63;
     const int r = lane & 31;
     const int h = lane >> 5;
+    constexpr bool SPLIT = EPI == EPI_RESIDUAL_SPLIT;
+    FW_STAMP_INIT();
 
     // ---- persistent workgroup: a contiguous range of tiles ---------------------------------------------------
     // Blocks b and b+8 share an XCD (and its L2): logical id lb puts the blocks of one XCD on a contiguous band of
@@ -58,7 +60,13 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
     const int ups = p.upsample2x;
     const int Ws = ups ? (p.W >> 1) : p.W;
     int rel[ACT_ITERS];  // element offset of this lane's piece from the tile origin (may be negative)
-    int rp[ACT_ITERS];   // (halo row << 8) | halo px, or -1 for the pad pieces
+    // halo position (row, px) of piece i of this lane; row = -1 for the pad pieces behind the 18x34 image
+    auto piece_pos = [&](int i, int* row, int* px) {
+        const int idx = (wave + NWAVES * i) * 64 + lane;
+        const int rw = idx / ROW_PIECES;
+        *px = (idx - rw * ROW_PIECES) >> 2;
+        *row = (idx < ACT_PIECES) ? rw : -1;
+    };
 #pragma unroll
     for (int i = 0; i < ACT_ITERS; ++i) {
         const int idx = (wave + NWAVES * i) * 64 + lane;
@@ -69,42 +77,47 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
         const int srow = ups ? ((row - 1) >> 1) : (row - 1);
         const int spx = ups ? ((px - 1) >> 1) : (px - 1);
         rel[i] = (srow * Ws + spx) * p.in_cstride + s * 8;
-        rp[i] = (idx < ACT_PIECES) ? ((row << 8) | px) : -1;
     }
     const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)lds;
     const T* in = reinterpret_cast<const T*>(p.in);
     const char* w_b = reinterpret_cast<const char*>(p.wpk) + lane * 16;
-    const unsigned chunk_bytes = (unsigned)(p.in_pstride * 2);
+    const long chunk_bytes = p.in_pstride * 2;
 
-    // The activation DMA stream runs NA-1 items ahead of the compute and walks (tile, chunk) in order: a_t/a_c
-    // is the item it issues next, src[]/inc[] the per-lane source of that item (zero page outside the image).
-    const char* src[ACT_ITERS];
-    unsigned inc[ACT_ITERS];
+    // The activation DMA stream runs NA-1 items ahead of the compute and walks (tile, chunk) in order: a_t/a_c is the item
+    // it issues next.  Per-lane state is rel[] plus one bit per piece (in the image / zero page), rebuilt per tile; the
+    // source of a piece is the wave-uniform plane address of (tile origin, chunk) plus rel[].
+    unsigned a_ok = 0;
+    const char* a_tile = nullptr;  // uniform: tile origin in chunk 0's plane
+    long a_coff = 0;               // uniform: byte offset of chunk a_c's plane from chunk 0's
     int a_n = 0, a_t = t_lo, a_c = 0;
     auto plan_tile = [&]() {
         const int ty0 = (a_t / tiles_x) * TILE_H, tx0 = (a_t % tiles_x) * TILE_W;
         const int sy0 = ups ? (ty0 >> 1) : ty0;
         const int sx0 = ups ? (tx0 >> 1) : tx0;
-        const T* base = in + ((long)sy0 * Ws + sx0) * p.in_cstride;
+        a_tile = reinterpret_cast<const char*>(in + ((long)sy0 * Ws + sx0) * p.in_cstride);
+        a_ok = 0;
 #pragma unroll
         for (int i = 0; i < ACT_ITERS; ++i) {
-            const int gy = ty0 - 1 + (rp[i] >> 8);
-            const int gx = tx0 - 1 + (rp[i] & 255);
-            const bool ok = rp[i] >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-            src[i] = ok ? reinterpret_cast<const char*>(base + rel[i]) : reinterpret_cast<const char*>(p.zeros);
-            inc[i] = ok ? chunk_bytes : 0u;
+            int row, px;
+            piece_pos(i, &row, &px);
+            const int gy = ty0 - 1 + row;
+            const int gx = tx0 - 1 + px;
+            if (row >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) a_ok |= 1u << i;
         }
     };
     // DMA number i (0..ACT_ITERS-1) of the next activation item
     auto issue_act_one = [&](int i) {
         if (i == 0 && a_c == 0) plan_tile();
-        glds16(src[i], lds_base + (unsigned)((a_n % NA) * ACT_REGION + (wave + NWAVES * i) * 64) * 16u);
-        src[i] += inc[i];
+        const char* s = ((a_ok >> i) & 1u) ? a_tile + a_coff + (long)rel[i] * 2 : reinterpret_cast<const char*>(p.zeros);
+        glds16(s, lds_base + (unsigned)((a_n % NA) * ACT_REGION + (wave + NWAVES * i) * 64) * 16u);
         if (i == ACT_ITERS - 1) {
             ++a_n;
             if (++a_c == nch) {
                 a_c = 0;
+                a_coff = 0;
                 ++a_t;
+            } else {
+                a_coff += chunk_bytes;
             }
         }
     };
@@ -135,12 +148,46 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
             for (int ct = 0; ct < CT; ++ct) f.w[dy][ct] = wl[(((dy * 3 + dx) * 2 + ks) * CT + ct) * 64];
     };
 
+    // identity A-fragment (SPLIT): row = cout r, k = 16*ks + 8*h + j  ->  1 where cout == k, as a lane-private bit mask
+    // over (ks, j); scaled per chunk when used
+    unsigned id_mask = 0;
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (r == 16 * ks + 8 * h + j) id_mask |= 1u << (8 * ks + j);
+    }
+
     f32x16 acc[RPW][CT];
-    f32x16 bias_v[CT];
+    // CT == 1 keeps the bias in registers; with 64 output channels the accumulators need the room and the bias is re-read
+    // per tile (256 B from L1/L2)
+    f32x16 bias_v[1];  // dead (and eliminated) when CT == 2
+    if constexpr (CT == 1) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+        for (int i = 0; i < 16; ++i) bias_v[0][i] = p.bias[(i & 3) + 8 * (i >> 2) + 4 * h];
+    }
+
+    // SPLIT: acc[row][ct] += sc * xf (32 channels of the wave's RPW x 32 pixels as B fragments [row][ks]): 4 MFMAs with a
+    // scaled identity A-fragment.  Products are exact, the sum is fp32.
+    auto add_identity = [&](const uint4 (&xf)[RPW][2], float sc, int ct) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) bias_v[ct][i] = p.bias[32 * ct + (i & 3) + 8 * (i >> 2) + 4 * h];
+        for (int ks = 0; ks < 2; ++ks) {
+            float e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = ((id_mask >> (8 * ks + j)) & 1u) ? sc : 0.f;
+            const uint2 lo4 = Op<T>::pack4(e[0], e[1], e[2], e[3]);
+            const uint2 hi4 = Op<T>::pack4(e[4], e[5], e[6], e[7]);
+            const uint4 idf = make_uint4(lo4.x, lo4.y, hi4.x, hi4.y);
+#pragma unroll
+            for (int row = 0; row < RPW; ++row) {
+                if (ct)
+                    acc[row][CT - 1] = Op<T>::mfma(idf, xf[row][ks], acc[row][CT - 1]);
+                else
+                    acc[row][0] = Op<T>::mfma(idf, xf[row][ks], acc[row][0]);
+            }
+        }
+    };
 
     // ---- pipeline prologue ------------------------------------------------------------------------------------
     // Issue order per boundary is [weights(n+1), activations(n+NA-1)]; vmcnt retires in order, so at boundary n
@@ -163,10 +210,20 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
     for (int t = t_lo; t < t_hi; ++t) {
         const int y0 = (t / tiles_x) * TILE_H;
         const int x0 = (t % tiles_x) * TILE_W;
+        if constexpr (CT == 1) {
 #pragma unroll
-        for (int row = 0; row < RPW; ++row)
+            for (int row = 0; row < RPW; ++row) acc[row][0] = bias_v[0];
+        } else {
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) acc[row][ct] = bias_v[ct];
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float bv = p.bias[32 * ct + (i & 3) + 8 * (i >> 2) + 4 * h];
+#pragma unroll
+                    for (int row = 0; row < RPW; ++row) acc[row][ct][i] = bv;
+                }
+        }
+        FW_STAMP(4);  // tile setup
 
         for (int c = 0; c < nch; ++c, ++n) {
             // item n has landed (each wave waits for its own DMAs, then the barrier) and every wave is done reading
@@ -175,7 +232,9 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
                 asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // ACT_ITERS: activations(n+1) may stay in flight
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FW_STAMP(5);  // this wave's own DMAs
             __syncthreads();
+            FW_STAMP(0);  // barrier
             const bool do_w = n + 1 < nitems && !(dbg & 2);
             const bool do_a = n + NA - 1 < nitems && !(dbg & 2);
             const int c1 = (c + 1 == nch) ? 0 : c + 1;
@@ -205,6 +264,25 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
 
             const uint4* a = lds + (n % NA) * ACT_REGION;
             const uint4* wl = lds + SM::W_BASE + (n & 1) * SM::W_REGION + lane;
+            // SPLIT: residual plane c (c < n_id) goes straight from HBM to B-fragment registers - lane (pixel r, half h)
+            // takes channels [16ks + 8h, +8) of its two pixels - issued now, consumed after the item's MFMAs: no LDS, no
+            // halo, and the latency hides under the item.
+            uint4 idx[RPW][2];
+            const bool has_id = SPLIT && c < p.n_id;
+            if constexpr (SPLIT) {
+                if (has_id) {
+                    const char* plane = reinterpret_cast<const char*>(p.in) + p.chunk_off[c];
+#pragma unroll
+                    for (int row = 0; row < RPW; ++row) {
+                        const int y = y0 + RPW * wave + row, x = x0 + r;
+                        const bool inside = y < p.H && x < p.W;
+                        const char* px = plane + (((size_t)y * p.W + x) * p.in_cstride + 8 * h) * 2;
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks)
+                            idx[row][ks] = inside ? *reinterpret_cast<const uint4*>(px + 32 * ks) : make_uint4(0, 0, 0, 0);
+                    }
+                }
+            }
             // register double buffer: the next group's ds_reads fly under this group's MFMAs.  sched_barrier(0)
             // pins that order: left alone, hipcc sinks every ds_read to just before its first use, and with one wave
             // per SIMD each group then eats a full LDS round trip.
@@ -233,6 +311,18 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
             FW_SB();
             mfma_group(fb, 5);
             FW_SB();
+            if constexpr (SPLIT) {
+                if (c < CT && p.in_id_scale != 0.f) {  // the conv's own input channels [32c, 32c+32): centre tap of the tile in LDS
+                    uint4 xf[RPW][2];
+#pragma unroll
+                    for (int row = 0; row < RPW; ++row)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) xf[row][ks] = a[(row + 1) * ROW_PIECES + rd_off[1][ks]];
+                    add_identity(xf, p.in_id_scale, c);
+                }
+                if (has_id) add_identity(idx, p.id_scale[c], c & 1);
+            }
+            FW_STAMP(1);  // item compute
         }
 
         // ---- epilogue (the DMA stream is already fetching the next tile) -----------------------------------------
@@ -261,6 +351,12 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
             }
         } else {
             constexpr int NC = 32 * CT;
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int row = 0; row < RPW; ++row)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) acc[row][ct] = acc[row][ct] * p.s1;
+            } else {
             // (1) fp32 side: residuals in, trunk out.  Native layout = the accumulator fragment order
             //     [tile][wave][row][ct][g][lane][4], one contiguous KiB per wave-instruction, no transposition;
             //     NHWC (op-level API) is the slow general form.
@@ -301,6 +397,8 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
                         for (int j = 0; j < 4; ++j) acc[row][ct][4 * g + j] = o[j];
                     }
             }
+            }
+            FW_STAMP(3);  // fp32-side epilogue
             // (2) typed NHWC output: transpose each row through LDS so that one wave-instruction stores whole
             //     pixels (16 B per lane, contiguous).  Scratch = a private 4352-byte slice of the activation stage just
             //     consumed (every wave has finished reading it after the barrier; it is refilled only after the next
@@ -308,18 +406,25 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
             if (p.out) {
                 constexpr int PSTR = CT == 1 ? 80 : 136;   // bytes per pixel in scratch (padded: conflict-free writes)
                 __syncthreads();
+                FW_STAMP(0);
                 char* scr = reinterpret_cast<char*>(lds + ((n - 1) % NA) * ACT_REGION) + wave * 4352;
-                T* outp = reinterpret_cast<T*>(p.out);
+                // pass 0: the typed output; pass 1 (64-channel convs feeding a split trunk): lo = T(y - T(y)) into out_lo
+                const int npass = (CT == 2 && p.out_lo) ? 2 : 1;
+                for (int pass = 0; pass < npass; ++pass) {
+                T* outp = reinterpret_cast<T*>(pass ? p.out_lo : p.out);
 #pragma unroll
                 for (int row = 0; row < RPW; ++row) {
                     const int y = y0 + RPW * wave + row;
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g)
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4 o = {acc[row][ct][4 * g], acc[row][ct][4 * g + 1], acc[row][ct][4 * g + 2],
+                                       acc[row][ct][4 * g + 3]};
+                            if (pass) o = o - Op<T>::unpack4(Op<T>::pack4(o[0], o[1], o[2], o[3]));
                             *reinterpret_cast<uint2*>(scr + r * PSTR + ct * 64 + (8 * g + 4 * h) * 2) =
-                                Op<T>::pack4(acc[row][ct][4 * g], acc[row][ct][4 * g + 1], acc[row][ct][4 * g + 2],
-                                             acc[row][ct][4 * g + 3]);
+                                Op<T>::pack4(o[0], o[1], o[2], o[3]);
+                        }
                     constexpr int LPP = 4 * CT;  // lanes per pixel (16 B each)
                     constexpr int PPI = 64 / LPP;
 #pragma unroll
@@ -342,12 +447,32 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
                         }
                     }
                 }
+                }
             }
+            FW_STAMP(6);  // typed store through LDS
         }
     }
+    if constexpr (CT == 2 && (EPI == EPI_RESIDUAL || SPLIT)) FW_STAMP_FLUSH(p.stamps);
 }
 
 #undef FW_SB
+
+#ifdef FW_PAIR_STAMP
+unsigned long long* stamp_buffer(int which) {
+    static unsigned long long* buf[2] = {nullptr, nullptr};
+    if (!buf[which]) {
+        FW_HIP_CHECK(hipMalloc((void**)&buf[which], 512));
+        FW_HIP_CHECK(hipMemset(buf[which], 0, 512));
+    }
+    return buf[which];
+}
+extern "C" int fw_debug_stamps(int which, unsigned long long* out) {
+    if (which < 0 || which > 1) return 1;
+    if (hipMemcpy(out, stamp_buffer(which), 512, hipMemcpyDeviceToHost) != hipSuccess) return 3;
+    (void)hipMemset(stamp_buffer(which), 0, 512);
+    return 0;
+}
+#endif
 
 static_assert(ACT_ITERS == 5, "the counted s_waitcnt vmcnt(5) in the kernel assumes 5 activation DMAs per wave");
 
@@ -398,6 +523,8 @@ static void launch_typed(int cout_tiles, ConvEpilogue epi, const ConvParams& p, 
         hipLaunchKernelGGL((conv3x3_mfma_kernel<T, 2, EPI_STORE>), grid, block, 0, stream, p);
     else if (cout_tiles == 2 && epi == EPI_RESIDUAL)
         hipLaunchKernelGGL((conv3x3_mfma_kernel<T, 2, EPI_RESIDUAL>), grid, block, 0, stream, p);
+    else if (cout_tiles == 2 && epi == EPI_RESIDUAL_SPLIT)
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<T, 2, EPI_RESIDUAL_SPLIT>), grid, block, 0, stream, p);
     else if (cout_tiles == 1 && epi == EPI_IMAGE)
         hipLaunchKernelGGL((conv3x3_mfma_kernel<T, 1, EPI_IMAGE>), grid, block, 0, stream, p);
     else
@@ -408,6 +535,9 @@ static void launch_typed(int cout_tiles, ConvEpilogue epi, const ConvParams& p, 
 void launch_conv3x3(DType dt, int cout_tiles, ConvEpilogue epi, const ConvParams& p_in, hipStream_t stream) {
     ConvParams p = p_in;
     p.zeros = zero_page();
+#ifdef FW_PAIR_STAMP
+    p.stamps = stamp_buffer(1);
+#endif
 
 
     if (p.H <= 0 || p.W <= 0 || p.cin_chunks <= 0) throw Error(1, "conv3x3: empty problem");
@@ -418,6 +548,14 @@ void launch_conv3x3(DType dt, int cout_tiles, ConvEpilogue epi, const ConvParams
     if (p.out && cout_tiles == 2 && (p.out_pstride < 32 || (p.out_pstride & 7)))
         throw Error(1, "conv3x3: bad output plane stride");
     if (p.out && ((p.out_cstride & 7) || (p.out_coff & 7))) throw Error(1, "conv3x3: output slice must be 16-byte aligned");
+    if (p.out_lo && (cout_tiles != 2 || !p.out || epi == EPI_IMAGE)) throw Error(1, "conv3x3: out_lo needs a 64-channel typed output");
+    if (epi == EPI_RESIDUAL_SPLIT) {
+        if (cout_tiles != 2 || p.upsample2x || !p.out || !p.out_lo || p.n_id < 0 || p.n_id > 6 || p.n_id > p.cin_chunks)
+            throw Error(1, "conv3x3: bad split-trunk residual problem");
+        for (int i = 0; i < p.n_id; ++i)
+            if (operand_to_f32(dt, f32_to_operand(dt, p.id_scale[i])) != p.id_scale[i])
+                throw Error(1, "conv3x3: identity scale not representable in the operand type");
+    }
     if (dt == DT_BF16)
         launch_typed<__bf16>(cout_tiles, epi, p, stream);
     else

@@ -24,20 +24,6 @@ namespace fw {
 #define FW_PAIR_DBG 0
 #endif
 
-// phase stamps (diagnostic build -DFW_PAIR_STAMP only): wave 0 of every block accumulates s_memtime deltas per phase
-#ifdef FW_PAIR_STAMP
-#define FW_STAMP(slot)                                                   \
-    do {                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                               \
-        const unsigned long long t_ = __builtin_amdgcn_s_memtime();      \
-        __builtin_amdgcn_sched_barrier(0);                               \
-        stamp_acc[slot] += t_ - stamp_last;                              \
-        stamp_last = t_;                                                 \
-    } while (0)
-#else
-#define FW_STAMP(slot) do { } while (0)
-#endif
-
 constexpr int PAIR_TH = TILE_H - 2;  // 14 valid rows per tile
 constexpr int PAIR_TW = TILE_W - 2;  // 30 valid pixels per tile row
 
@@ -65,11 +51,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
     const int lane = tid & 63;
     const int r = lane & 31;
     const int h = lane >> 5;
-#ifdef FW_PAIR_STAMP
-    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
-    const unsigned long long stamp_rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
+    FW_STAMP_INIT();
 
     const int NB = gridDim.x;
     const int xcd = blockIdx.x & 7;
@@ -312,29 +294,9 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
         if (!(FW_PAIR_DBG & 4)) emit(acc_b, lds + ((q - 1) & 1) * ACT_REGION, oy, ox, reinterpret_cast<T*>(p.out_b), false);
         FW_STAMP(3);
     }
-#ifdef FW_PAIR_STAMP
-    // slot 7: wall time of the wave in 100 MHz ticks -> in-kernel clock = sum(slots 0..5) / slot 7 * 100 MHz
-    stamp_acc[7] = __builtin_amdgcn_s_memrealtime() - stamp_rt0;
-    if (lane == 0 && p.stamps)
-        for (int k = 0; k < 8; ++k) atomicAdd(p.stamps + wave * 8 + k, stamp_acc[k]);
-#endif
+    FW_STAMP_FLUSH(p.stamps);
 }
 
-#ifdef FW_PAIR_STAMP
-static unsigned long long* pair_stamp_buffer() {
-    static unsigned long long* buf = nullptr;
-    if (!buf) {
-        FW_HIP_CHECK(hipMalloc((void**)&buf, 512));
-        FW_HIP_CHECK(hipMemset(buf, 0, 512));
-    }
-    return buf;
-}
-extern "C" int fw_debug_pair_stamps(unsigned long long* out) {
-    if (hipMemcpy(out, pair_stamp_buffer(), 512, hipMemcpyDeviceToHost) != hipSuccess) return 3;
-    (void)hipMemset(pair_stamp_buffer(), 0, 512);
-    return 0;
-}
-#endif
 
 static int pair_num_cus() {
     static int n = [] {
@@ -356,7 +318,7 @@ void launch_conv3x3_pair(DType dt, const ConvPairParams& p_in, hipStream_t strea
     if (!p.in || !p.wpk_a || !p.wpk_b || !p.bias_a || !p.bias_b || !p.out_a || !p.out_b) throw Error(1, "conv3x3_pair: NULL");
     p.zeros = conv_zero_page();
 #ifdef FW_PAIR_STAMP
-    p.stamps = pair_stamp_buffer();
+    p.stamps = stamp_buffer(0);
 #endif
     const int tiles = ((p.W + PAIR_TW - 1) / PAIR_TW) * ((p.H + PAIR_TH - 1) / PAIR_TH);
     dim3 grid(tiles < pair_num_cus() ? tiles : pair_num_cus()), block(64 * NWAVES);

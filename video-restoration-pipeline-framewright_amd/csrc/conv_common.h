@@ -23,6 +23,10 @@ struct Op<__bf16> {
         bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
         return __builtin_bit_cast(uint2, v);
     }
+    static __device__ __forceinline__ f32x4 unpack4(uint2 v) {
+        return f32x4{__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xffff0000u),
+                     __builtin_bit_cast(float, v.y << 16), __builtin_bit_cast(float, v.y & 0xffff0000u)};
+    }
 };
 template <>
 struct Op<_Float16> {
@@ -33,6 +37,10 @@ struct Op<_Float16> {
     static __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
         f16x4 v = {(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};
         return __builtin_bit_cast(uint2, v);
+    }
+    static __device__ __forceinline__ f32x4 unpack4(uint2 v) {
+        const f16x4 q = __builtin_bit_cast(f16x4, v);
+        return f32x4{(float)q[0], (float)q[1], (float)q[2], (float)q[3]};
     }
 };
 
@@ -92,6 +100,36 @@ struct Frags {
     uint4 x[RPW + 2];
     uint4 w[3][CT];
 };
+
+// Phase stamps (diagnostic build -DFW_PAIR_STAMP only; in the product build no stamp executes): every wave accumulates
+// s_memtime deltas per phase into 8 slots; slot 7 = the wave's lifetime in 100 MHz s_memrealtime ticks, so the clock the
+// chip held is sum(slots 0..6) / slot 7 * 100 MHz.  stamp_buffer(k): 8 waves x 8 slots of the pair kernel (k = 0) and the
+// 64-channel residual conv (k = 1).
+#ifdef FW_PAIR_STAMP
+#define FW_STAMP_INIT()                                                        \
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};                  \
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();              \
+    const unsigned long long stamp_rt0 = __builtin_amdgcn_s_memrealtime()
+#define FW_STAMP(slot)                                                   \
+    do {                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                               \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();      \
+        __builtin_amdgcn_sched_barrier(0);                               \
+        stamp_acc[slot] += t_ - stamp_last;                              \
+        stamp_last = t_;                                                 \
+    } while (0)
+#define FW_STAMP_FLUSH(buf)                                                                       \
+    do {                                                                                          \
+        stamp_acc[7] = __builtin_amdgcn_s_memrealtime() - stamp_rt0;                              \
+        if ((threadIdx.x & 63) == 0 && (buf))                                                     \
+            for (int k_ = 0; k_ < 8; ++k_) atomicAdd((buf) + (threadIdx.x >> 6) * 8 + k_, stamp_acc[k_]); \
+    } while (0)
+unsigned long long* stamp_buffer(int which);
+#else
+#define FW_STAMP_INIT() do { } while (0)
+#define FW_STAMP(slot) do { } while (0)
+#define FW_STAMP_FLUSH(buf) do { } while (0)
+#endif
 
 #ifdef FW_NO_SB
 #define FW_SB()

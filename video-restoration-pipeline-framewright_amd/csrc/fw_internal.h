@@ -20,6 +20,14 @@ enum ConvEpilogue : int {
     EPI_STORE = 0,     // y = act(acc + bias)                    -> typed NHWC slice (+ optional fp32 copy)
     EPI_RESIDUAL = 1,  // y = (acc+bias)*s1 + res1 [; y = y*s2 + res2] -> fp32 trunk + typed NHWC slice
     EPI_IMAGE = 2,     // 3 output channels: RGB float and/or clamp->x255->rint->uint8 BGR
+    // The RRDB trunk kept as a pair of operand-typed tensors instead of fp32: hi = T(x) (the typed planes every conv reads
+    // anyway) and lo = T(x - hi), both chunk-planar.  hi + lo carries 16 (bf16) / 22 (f16) mantissa bits.  The residual
+    // add runs on the matrix cores: while it contracts conv chunk c the kernel also loads residual plane c (c < n_id)
+    // straight into B-fragment registers and accumulates it as id_scale[c] * I (exact products, fp32 accumulate), so the
+    // epilogue loads nothing:
+    //   y = s1 * (acc + bias + in_id_scale * in[0:64] + sum_c id_scale[c] * plane_c)  ->  out (hi planes) + out_lo (lo planes)
+    // 64 output channels; residual plane c feeds output channels [32*(c&1), 32*(c&1)+32).
+    EPI_RESIDUAL_SPLIT = 3,
 };
 
 struct ConvParams {
@@ -49,6 +57,14 @@ struct ConvParams {
     int f32_cstride;       // NHWC fp32 side buffers: floats per pixel (0 = 32*cout_tiles) and first channel
     int f32_coff;
     int f32_native;        // 1: res1/res2/out_f32 use the accumulator-native layout (see f32_native_elems)
+    // split trunk (EPI_RESIDUAL_SPLIT; out_lo also with 64-channel EPI_STORE): lo planes, strides of `out`
+    void* out_lo;
+    int n_id;              // residual planes (EPI_RESIDUAL_SPLIT), <= min(6, cin_chunks)
+    float id_scale[6];     // exactly representable in the operand type
+    float in_id_scale;     // EPI_RESIDUAL_SPLIT: conv chunks 0,1 (the conv's own input channels [0,64)) are also added as
+                           // in_id_scale * I, from the tile already in LDS (0 = off)
+    long chunk_off[6];     // EPI_RESIDUAL_SPLIT: byte offset of residual plane c from `in`; pixel stride = in_cstride
+    unsigned long long* stamps;  // diagnostic builds only (-DFW_PAIR_STAMP)
     const void* zeros;     // >= 16 bytes of zeros in device memory (set by launch_conv3x3)
 };
 

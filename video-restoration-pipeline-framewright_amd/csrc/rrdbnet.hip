@@ -51,6 +51,9 @@ struct fw_rrdbnet {
     std::vector<ConvLayer> body;  // [num_block][3][5]
     Workspace ws;
     bool fuse_pairs = true;  // conv1+conv2 / conv3+conv4 in one kernel (FW_RRDB_FUSE_PAIRS=0 disables, for A/B runs)
+    // residual trunk as typed hi + typed lo planes (EPI_RESIDUAL_SPLIT): the residual adds run on the matrix cores as
+    // identity chunks and conv5's epilogue loads nothing (FW_RRDB_SPLIT_TRUNK=0 selects the fp32 trunk, for A/B runs)
+    bool split_trunk = true;
     // profiling
     bool profile = false;
     std::vector<hipEvent_t> ev_pool;
@@ -106,7 +109,7 @@ void trunk_size(const fw_rrdbnet* n, int H, int W, int* Ht, int* Wt) {
 }
 
 struct Plan {
-    size_t in_u8, out_u8, in32, cat0, cat1, F, R, tA, tB, U1, U2, U3, total;
+    size_t in_u8, out_u8, in32, cat0, cat1, cat2, F, R, tA, tB, U1, U2, U3, total;
 };
 
 Plan make_plan(const fw_rrdbnet* n, int H, int W) {
@@ -124,13 +127,20 @@ Plan make_plan(const fw_rrdbnet* n, int H, int W) {
     p.in_u8 = take((size_t)H * W * 3);
     p.out_u8 = take((size_t)H * W * 3 * s * s);
     p.in32 = take(px * 32 * 2);
-    p.cat0 = take(px * 192 * 2);
-    p.cat1 = take(px * 192 * 2);
+    // concat buffers: 6 planes of 32 channels (x, x1..x4); the split trunk adds planes 6-7 (lo part of x) and a third
+    // buffer, which keeps the RRDB input alive until rdb3's second residual
+    const size_t cat_bytes = px * (n->split_trunk ? 256 : 192) * 2;
+    p.cat0 = take(cat_bytes);
+    p.cat1 = take(cat_bytes);
     const size_t trunk = f32_native_elems(Ht, Wt, 2) * 4;  // fp32 trunk buffers, accumulator-native layout
     p.F = take(trunk);
-    p.R = take(trunk);
-    p.tA = take(trunk);
-    p.tB = take(trunk);
+    if (n->split_trunk) {
+        p.cat2 = take(cat_bytes);
+    } else {
+        p.R = take(trunk);
+        p.tA = take(trunk);
+        p.tB = take(trunk);
+    }
     p.U1 = take(px * 4 * 64 * 2);
     p.U2 = take(px * 16 * 64 * 2);
     p.U3 = take(px * 16 * 64 * 2);
@@ -214,7 +224,9 @@ void forward(fw_rrdbnet* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, f
     const Plan pl = make_plan(n, H, W);
     char* ws = n->ws.base;
     void* in32 = ws + pl.in32;
-    void* cat[2] = {ws + pl.cat0, ws + pl.cat1};
+    void* cat[3] = {ws + pl.cat0, ws + pl.cat1, ws + pl.cat2};
+    const int ncat = n->split_trunk ? 3 : 2;
+
     float* F = (float*)(ws + pl.F);
     float* R = (float*)(ws + pl.R);
     float* tA = (float*)(ws + pl.tA);
@@ -245,12 +257,14 @@ void forward(fw_rrdbnet* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, f
         p.in = in32;
         p.out = cat[0];
         p.out_f32 = F;
+        if (n->split_trunk) p.out_lo = plane(cat[0], 6, PL);
         run_conv(n, n->conv_first, EPI_STORE, p, st);
     }
 
     int cur = 0;
     for (int b = 0; b < n->num_block; ++b) {
         const float* Rin = (b == 0) ? F : R;
+        const int rrdb_in = cur;  // split trunk: planes 0-1 of this buffer stay the RRDB input until rdb3 overwrites them
         for (int k = 0; k < 3; ++k) {
             const ConvLayer* L = &n->body[((size_t)b * 3 + k) * 5];
             // conv1..conv4: growth channels, LeakyReLU(0.2), written into the next plane    (:184-187);
@@ -284,19 +298,45 @@ void forward(fw_rrdbnet* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, f
             }
             // conv5 + residual(s): x5*0.2 + x  (:188-189); after rdb3 additionally *0.2 + rrdb_in (:204)
             ConvParams p = base;
+            const int nxt = (cur + 1) % ncat;
             p.in = cat[cur];
-            p.out = cat[cur ^ 1];
+            p.out = cat[nxt];
             p.s1 = 0.2f;
-            p.res1 = (k == 0) ? Rin : (k == 1 ? tA : tB);
-            if (k == 2) {
-                p.res2 = Rin;
-                p.s2 = 0.2f;
-                p.out_f32 = R;
+            if (n->split_trunk) {
+                // y = 0.2*conv5 + x           = 0.2  * (conv5 + 5*x)            x = planes 0,1 (hi) + 6,7 (lo) of cat[cur]
+                // y = (0.2*conv5 + x)*0.2 + R = 0.04 * (conv5 + 5*x + 25*R)     R = the same planes of cat[rrdb_in]
+                // x hi is added from conv chunks 0,1 while they sit in LDS; residual planes: x lo (6,7) [, R hi (0,1), R lo
+                // (6,7)].  Each tile consumes its residual pixels before it stores, so rdb3 updates the RRDB input in place
+                // (nxt == rrdb_in).
+                const long PB = PL * 2;  // bytes per plane
+                const long r_off = (char*)cat[rrdb_in] - (char*)cat[cur];
+                p.out_lo = plane(cat[nxt], 6, PL);
+                p.in_id_scale = 5.f;
+                p.n_id = (k == 2) ? 6 : 2;
+                p.chunk_off[0] = 6 * PB;
+                p.chunk_off[1] = 7 * PB;
+                p.id_scale[0] = p.id_scale[1] = 5.f;
+                if (k == 2) {
+                    p.chunk_off[2] = r_off;              // R hi
+                    p.chunk_off[3] = r_off + PB;
+                    p.chunk_off[4] = r_off + 6 * PB;     // R lo
+                    p.chunk_off[5] = r_off + 7 * PB;
+                    for (int i = 2; i < 6; ++i) p.id_scale[i] = 25.f;
+                }
+                p.s1 = (k == 2) ? 0.2f * 0.2f : 0.2f;
+                run_conv(n, L[4], EPI_RESIDUAL_SPLIT, p, st);
             } else {
-                p.out_f32 = (k == 0) ? tA : tB;
+                p.res1 = (k == 0) ? Rin : (k == 1 ? tA : tB);
+                if (k == 2) {
+                    p.res2 = Rin;
+                    p.s2 = 0.2f;
+                    p.out_f32 = R;
+                } else {
+                    p.out_f32 = (k == 0) ? tA : tB;
+                }
+                run_conv(n, L[4], EPI_RESIDUAL, p, st);
             }
-            run_conv(n, L[4], EPI_RESIDUAL, p, st);
-            cur ^= 1;
+            cur = nxt;
         }
     }
 
@@ -304,11 +344,11 @@ void forward(fw_rrdbnet* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, f
     {
         ConvParams p = base;
         p.in = cat[cur];
-        p.out = cat[cur ^ 1];
+        p.out = cat[(cur + 1) % ncat];
         p.res1 = F;
         p.s1 = 1.f;
         run_conv(n, n->conv_body, EPI_RESIDUAL, p, st);
-        cur ^= 1;
+        cur = (cur + 1) % ncat;
     }
     // lrelu(conv_up1(nearest x2)), lrelu(conv_up2(nearest x2))                    (:260-266)
     {
@@ -391,6 +431,7 @@ int fw_rrdbnet_create(int device_id, int num_block, int scale, int dtype, fw_rrd
         n->dt = (DType)dtype;
         n->body.resize((size_t)num_block * 15);
         if (const char* e = getenv("FW_RRDB_FUSE_PAIRS")) n->fuse_pairs = atoi(e) != 0;
+        if (const char* e = getenv("FW_RRDB_SPLIT_TRUNK")) n->split_trunk = atoi(e) != 0;
         *out = n.release();
     });
 }
