@@ -8,7 +8,7 @@
 A "step" is one frame through the whole hot path (uint8 BGR 1920x1080 resident in HBM -> uint8 BGR 7680x4320 in
 HBM).  Frames are independent, so N ranks each process K frames of their round-robin shard (weak scaling, no
 data-path collective); rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around every conv
-launch (the MFMA implicit-GEMM kernel is >99 % of the FLOPs); `cpu_baseline` times the fp32 CPU oracle on a bounded
+launch (the MFMA implicit-GEMM kernels are >99 % of the FLOPs); `cpu_baseline` times the fp32 CPU oracle on a bounded
 crop on rank 0 at N=1.
 """
 from __future__ import annotations
@@ -165,7 +165,7 @@ def main():
             "whole_path_tflops_per_gpu": flops_frame * args.steps / (dev_ms * 1e-3) / 1e12,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_note,
-                         "kernel": "conv3x3_mfma_kernel (all instantiations)",
+                         "kernel": "conv3x3_mfma_kernel + conv3x3_pair_kernel (all instantiations)",
                          "launches_timed": launches, "avg_launch_ms": conv_ms / max(launches, 1),
                          "avg_launch_gflop": conv_flops / max(launches, 1) / 1e9},
         }

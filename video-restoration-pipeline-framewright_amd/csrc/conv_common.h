@@ -16,8 +16,17 @@ struct Op;
 template <>
 struct Op<__bf16> {
     static __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
+#ifdef FW_MFMA16_TIMING  // timing experiment only (wrong results): the same FLOPs as two 16x16x32 MFMAs
+        f32x4 c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c1, 0, 0, 0);
+        c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3];
+        c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
+        return c;
+#else
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
                                                        0, 0, 0);
+#endif
     }
     static __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
         bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
