@@ -32,12 +32,13 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
     using SM = Smem<CT>;
     __shared__ __attribute__((aligned(16))) uint4 lds[SM::TOTAL];
     constexpr int NA = SM::NA;
+    constexpr int NW = 2 * CT;  // accumulator tiles of 16 output channels
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int r = lane & 31;
-    const int h = lane >> 5;
+    const int q = lane & 15;   // pixel within a 16-pixel half row (B/D column), output channel within a tile (A row)
+    const int sl = lane >> 4;  // 8-channel slot of the 32-channel chunk (A/B k index), 4-channel group of the D tile
     constexpr bool SPLIT = EPI == EPI_RESIDUAL_SPLIT;
     FW_STAMP_INIT();
 
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
         const int row = idx / ROW_PIECES;
         const int rm = idx - row * ROW_PIECES;
         const int px = rm >> 2;
-        const int s = (rm & 3) ^ ((px >> 2) & 3);  // which 8-channel slot lands at this LDS position
+        const int s = (rm & 3) ^ halo_swz(px);  // which 8-channel slot lands at this LDS position
         const int srow = ups ? ((row - 1) >> 1) : (row - 1);
         const int spx = ups ? ((px - 1) >> 1) : (px - 1);
         rel[i] = (srow * Ws + spx) * p.in_cstride + s * 8;
@@ -131,61 +132,48 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
     };
 
     // ---- fragment-read plan ------------------------------------------------------------------------------------
-    int rd_off[3][2];  // [dx][ks]: piece index of (halo row RPW*wave, px r+dx, k-step ks) for this lane
+    int rd_off[3][2];  // [dx][ph]: piece index of (halo row RPW*wave, px 16*ph + q + dx, slot sl) for this lane
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            rd_off[dx][ks] = (RPW * wave) * ROW_PIECES + (r + dx) * 4 + ((2 * ks + h) ^ (((r + dx) >> 2) & 3));
+        for (int ph = 0; ph < 2; ++ph) {
+            const int px = 16 * ph + q + dx;
+            rd_off[dx][ph] = (RPW * wave) * ROW_PIECES + px * 4 + (sl ^ halo_swz(px));
+        }
 
-    auto load_group = [&](Frags<CT>& f, const uint4* a, const uint4* wl, int g) {
-        const int ks = g / 3, dx = g - ks * 3;
-#pragma unroll
-        for (int row = 0; row < RPW + 2; ++row) f.x[row] = a[row * ROW_PIECES + rd_off[dx][ks]];
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) f.w[dy][ct] = wl[(((dy * 3 + dx) * 2 + ks) * CT + ct) * 64];
-    };
-
-    // identity A-fragment (SPLIT): row = cout r, k = 16*ks + 8*h + j  ->  1 where cout == k, as a lane-private bit mask
-    // over (ks, j); scaled per chunk when used
+    // identity A-fragments (SPLIT): tile ctl of a 32-channel residual plane, row = cout 16*ctl + q, k = 8*sl + j -> 1 where
+    // cout == k, as a lane-private bit mask over (ctl, j); scaled per plane when used
     unsigned id_mask = 0;
     if constexpr (SPLIT) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ctl = 0; ctl < 2; ++ctl)
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (r == 16 * ks + 8 * h + j) id_mask |= 1u << (8 * ks + j);
+                if (16 * ctl + q == 8 * sl + j) id_mask |= 1u << (8 * ctl + j);
     }
 
-    f32x16 acc[RPW][CT];
-    // CT == 1 keeps the bias in registers; with 64 output channels the accumulators need the room and the bias is re-read
-    // per tile (256 B from L1/L2)
-    f32x16 bias_v[1];  // dead (and eliminated) when CT == 2
-    if constexpr (CT == 1) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) bias_v[0][i] = p.bias[(i & 3) + 8 * (i >> 2) + 4 * h];
-    }
+    f32x4 acc[RPW][NW][2];  // [row][16-channel tile][16-pixel half]: pixel 16*ph + q, channels 16*w + 4*sl + j
 
-    // SPLIT: acc[row][ct] += sc * xf (32 channels of the wave's RPW x 32 pixels as B fragments [row][ks]): 4 MFMAs with a
-    // scaled identity A-fragment.  Products are exact, the sum is fp32.
-    auto add_identity = [&](const uint4 (&xf)[RPW][2], float sc, int ct) {
+    // SPLIT: acc[row][2*c2 + ctl][ph] += sc * xf[row][ph] (32 channels of the wave's RPW x 32 pixels as B fragments): 8 MFMAs
+    // with scaled identity A-fragments.  Products are exact, the sum is fp32.
+    auto add_identity = [&](const uint4 (&xf)[RPW][2], float sc, int c2) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ctl = 0; ctl < 2; ++ctl) {
             float e[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) e[j] = ((id_mask >> (8 * ks + j)) & 1u) ? sc : 0.f;
+            for (int j = 0; j < 8; ++j) e[j] = ((id_mask >> (8 * ctl + j)) & 1u) ? sc : 0.f;
             const uint2 lo4 = Op<T>::pack4(e[0], e[1], e[2], e[3]);
             const uint2 hi4 = Op<T>::pack4(e[4], e[5], e[6], e[7]);
             const uint4 idf = make_uint4(lo4.x, lo4.y, hi4.x, hi4.y);
 #pragma unroll
-            for (int row = 0; row < RPW; ++row) {
-                if (ct)
-                    acc[row][CT - 1] = Op<T>::mfma(idf, xf[row][ks], acc[row][CT - 1]);
-                else
-                    acc[row][0] = Op<T>::mfma(idf, xf[row][ks], acc[row][0]);
-            }
+            for (int row = 0; row < RPW; ++row)
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) {
+                    if (c2)
+                        acc[row][NW - 2 + ctl][ph] = Op<T>::mfma16(idf, xf[row][ph], acc[row][NW - 2 + ctl][ph]);
+                    else
+                        acc[row][ctl][ph] = Op<T>::mfma16(idf, xf[row][ph], acc[row][ctl][ph]);
+                }
         }
     };
 
@@ -201,7 +189,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
         for (int i = 0; i < ACT_ITERS; ++i) issue_act_one(i);
     }
 
-    // timing ablations: build with -DFW_CONV_DEBUG=<bits> (1 = no MFMA, 2 = no LDS-DMA, 4 = no epilogue)
+    // timing ablations: build with -DFW_CONV_DEBUG=<bits> (2 = no LDS-DMA, 4 = no epilogue)
 #ifndef FW_CONV_DEBUG
 #define FW_CONV_DEBUG 0
 #endif
@@ -210,18 +198,14 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
     for (int t = t_lo; t < t_hi; ++t) {
         const int y0 = (t / tiles_x) * TILE_H;
         const int x0 = (t % tiles_x) * TILE_W;
-        if constexpr (CT == 1) {
+        // accumulators start at the bias (re-read per tile: <= 256 B from L1/L2, cheaper than live registers)
 #pragma unroll
-            for (int row = 0; row < RPW; ++row) acc[row][0] = bias_v[0];
-        } else {
+        for (int w = 0; w < NW; ++w) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + 16 * w + 4 * sl);
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
+            for (int row = 0; row < RPW; ++row)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float bv = p.bias[32 * ct + (i & 3) + 8 * (i >> 2) + 4 * h];
-#pragma unroll
-                    for (int row = 0; row < RPW; ++row) acc[row][ct][i] = bv;
-                }
+                for (int ph = 0; ph < 2; ++ph) acc[row][w][ph] = bv;
         }
         FW_STAMP(4);  // tile setup
 
@@ -238,9 +222,8 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
             const bool do_w = n + 1 < nitems && !(dbg & 2);
             const bool do_a = n + NA - 1 < nitems && !(dbg & 2);
             const int c1 = (c + 1 == nch) ? 0 : c + 1;
-            // The W_ITERS + ACT_ITERS DMAs of this boundary are issued one at a time in the shadow of the MFMAs
-            // (an MFMA occupies the issue port for 8 of its 32 cycles): slot d of group gi, compile-time after
-            // unrolling.
+            // The W_ITERS + ACT_ITERS DMAs of this boundary are issued one at a time in the shadow of the MFMAs: slot d,
+            // compile-time after unrolling.
             auto dma_slot = [&](int d) {
                 if (d < SM::W_ITERS) {
                     if (do_w) issue_w_one(d, c1, (n + 1) & 1);
@@ -248,24 +231,11 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
                     if (do_a) issue_act_one(d - SM::W_ITERS);
                 }
             };
-            auto mfma_group = [&](const Frags<CT>& f, int gi) {
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                    for (int row = 0; row < RPW; ++row) {
-#pragma unroll
-                        for (int ct = 0; ct < CT; ++ct)
-                            if (!(dbg & 1)) acc[row][ct] = Op<T>::mfma(f.w[dy][ct], f.x[row + dy], acc[row][ct]);
-                        FW_SB();
-                        dma_slot(gi * 6 + dy * 2 + row);
-                        FW_SB();
-                    }
-            };
 
             const uint4* a = lds + (n % NA) * ACT_REGION;
             const uint4* wl = lds + SM::W_BASE + (n & 1) * SM::W_REGION + lane;
-            // SPLIT: residual plane c (c < n_id) goes straight from HBM to B-fragment registers - lane (pixel r, half h)
-            // takes channels [16ks + 8h, +8) of its two pixels - issued now, consumed after the item's MFMAs: no LDS, no
+            // SPLIT: residual plane c (c < n_id) goes straight from HBM to B-fragment registers - lane (pixel 16*ph + q,
+            // slot sl) takes 8 channels of its two rows' pixels - issued now, consumed after the item's MFMAs: no LDS, no
             // halo, and the latency hides under the item.
             uint4 idx[RPW][2];
             const bool has_id = SPLIT && c < p.n_id;
@@ -273,53 +243,25 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
                 if (has_id) {
                     const char* plane = reinterpret_cast<const char*>(p.in) + p.chunk_off[c];
 #pragma unroll
-                    for (int row = 0; row < RPW; ++row) {
-                        const int y = y0 + RPW * wave + row, x = x0 + r;
-                        const bool inside = y < p.H && x < p.W;
-                        const char* px = plane + (((size_t)y * p.W + x) * p.in_cstride + 8 * h) * 2;
-#pragma unroll
-                        for (int ks = 0; ks < 2; ++ks)
-                            idx[row][ks] = inside ? *reinterpret_cast<const uint4*>(px + 32 * ks) : make_uint4(0, 0, 0, 0);
-                    }
-                }
-            }
-            // register double buffer: the next group's ds_reads fly under this group's MFMAs.  sched_barrier(0)
-            // pins that order: left alone, hipcc sinks every ds_read to just before its first use, and with one wave
-            // per SIMD each group then eats a full LDS round trip.
-            Frags<CT> fa, fb;
-            load_group(fa, a, wl, 0);
-            FW_SB();
-            load_group(fb, a, wl, 1);
-            FW_SB();
-            mfma_group(fa, 0);
-            FW_SB();
-            load_group(fa, a, wl, 2);
-            FW_SB();
-            mfma_group(fb, 1);
-            FW_SB();
-            load_group(fb, a, wl, 3);
-            FW_SB();
-            mfma_group(fa, 2);
-            FW_SB();
-            load_group(fa, a, wl, 4);
-            FW_SB();
-            mfma_group(fb, 3);
-            FW_SB();
-            load_group(fb, a, wl, 5);
-            FW_SB();
-            mfma_group(fa, 4);
-            FW_SB();
-            mfma_group(fb, 5);
-            FW_SB();
-            if constexpr (SPLIT) {
-                if (c < CT && p.in_id_scale != 0.f) {  // the conv's own input channels [32c, 32c+32): centre tap of the tile in LDS
-                    uint4 xf[RPW][2];
-#pragma unroll
                     for (int row = 0; row < RPW; ++row)
 #pragma unroll
-                        for (int ks = 0; ks < 2; ++ks) xf[row][ks] = a[(row + 1) * ROW_PIECES + rd_off[1][ks]];
-                    add_identity(xf, p.in_id_scale, c);
+                        for (int ph = 0; ph < 2; ++ph) {
+                            const int y = y0 + RPW * wave + row, x = x0 + 16 * ph + q;
+                            const bool inside = y < p.H && x < p.W;
+                            const char* px = plane + (((size_t)y * p.W + x) * p.in_cstride + 8 * sl) * 2;
+                            idx[row][ph] = inside ? *reinterpret_cast<const uint4*>(px) : make_uint4(0, 0, 0, 0);
+                        }
                 }
+            }
+            conv_item<T, NW, 0>(
+                acc, a, wl, rd_off, [](int tap, int w) { return tap * NW + w; }, dma_slot,
+                [&](const uint4 (&xc)[RPW][2]) {
+                    if constexpr (SPLIT) {
+                        // the conv's own input channels [32c, 32c+32) are a residual too: centre tap of the tile in LDS
+                        if (c < CT && p.in_id_scale != 0.f) add_identity(xc, p.in_id_scale, c);
+                    }
+                });
+            if constexpr (SPLIT) {
                 if (has_id) add_identity(idx, p.id_scale[c], c & 1);
             }
             FW_STAMP(1);  // item compute
@@ -328,75 +270,77 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
         // ---- epilogue (the DMA stream is already fetching the next tile) -----------------------------------------
         if (dbg & 4) continue;
         if constexpr (EPI == EPI_IMAGE) {
-            const int x = x0 + r;
+            // output channels 0..2 = R,G,B: tile 0, registers j = 0..2 of the lanes with sl == 0
 #pragma unroll
-            for (int row = 0; row < RPW; ++row) {
-                const int y = y0 + RPW * wave + row;
-                if (h == 0 && y < p.img_H && x < p.img_W && y < p.H && x < p.W) {
-                    const size_t pix = (size_t)y * p.img_W + x;
-                    const float cr = acc[row][0][0], cg = acc[row][0][1], cb = acc[row][0][2];
-                    if (p.out_rgb) {
-                        float* o = p.out_rgb + pix * 3;
-                        o[0] = cr;
-                        o[1] = cg;
-                        o[2] = cb;
-                    }
-                    if (p.out_u8) {
-                        uint8_t* o = p.out_u8 + pix * 3;
-                        o[0] = (uint8_t)rintf(fminf(fmaxf(cb, 0.f), 1.f) * 255.f);
-                        o[1] = (uint8_t)rintf(fminf(fmaxf(cg, 0.f), 1.f) * 255.f);
-                        o[2] = (uint8_t)rintf(fminf(fmaxf(cr, 0.f), 1.f) * 255.f);
+            for (int row = 0; row < RPW; ++row)
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) {
+                    const int y = y0 + RPW * wave + row;
+                    const int x = x0 + 16 * ph + q;
+                    if (sl == 0 && y < p.img_H && x < p.img_W && y < p.H && x < p.W) {
+                        const size_t pix = (size_t)y * p.img_W + x;
+                        const float cr = acc[row][0][ph][0], cg = acc[row][0][ph][1], cb = acc[row][0][ph][2];
+                        if (p.out_rgb) {
+                            float* o = p.out_rgb + pix * 3;
+                            o[0] = cr;
+                            o[1] = cg;
+                            o[2] = cb;
+                        }
+                        if (p.out_u8) {
+                            uint8_t* o = p.out_u8 + pix * 3;
+                            o[0] = (uint8_t)rintf(fminf(fmaxf(cb, 0.f), 1.f) * 255.f);
+                            o[1] = (uint8_t)rintf(fminf(fmaxf(cg, 0.f), 1.f) * 255.f);
+                            o[2] = (uint8_t)rintf(fminf(fmaxf(cr, 0.f), 1.f) * 255.f);
+                        }
                     }
                 }
-            }
         } else {
             constexpr int NC = 32 * CT;
             if constexpr (SPLIT) {
 #pragma unroll
                 for (int row = 0; row < RPW; ++row)
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) acc[row][ct] = acc[row][ct] * p.s1;
+                    for (int w = 0; w < NW; ++w)
+#pragma unroll
+                        for (int ph = 0; ph < 2; ++ph) acc[row][w][ph] = acc[row][w][ph] * p.s1;
             } else {
-            // (1) fp32 side: residuals in, trunk out.  Native layout = the accumulator fragment order
-            //     [tile][wave][row][ct][g][lane][4], one contiguous KiB per wave-instruction, no transposition;
-            //     NHWC (op-level API) is the slow general form.
+                // (1) fp32 side: residuals in, trunk out.  Native layout = the accumulator fragment order
+                //     [tile][wave][row][w][ph][lane][4], one contiguous KiB per wave-instruction, no transposition;
+                //     NHWC (op-level API) is the slow general form.
 #pragma unroll
-            for (int row = 0; row < RPW; ++row) {
-                const int y = y0 + RPW * wave + row;
-                const int x = x0 + r;
-                const bool inside = y < p.H && x < p.W;
-                const size_t pix = (size_t)y * p.W + x;
+                for (int row = 0; row < RPW; ++row)
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
+                    for (int w = 0; w < NW; ++w)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const size_t nat = ((((((size_t)t * NWAVES + wave) * RPW + row) * CT + ct) * 4 + g) * 64 + lane) * 4;
-                        const size_t lin = pix * (p.f32_cstride ? p.f32_cstride : NC) + p.f32_coff + 32 * ct + 8 * g + 4 * h;
-                        const size_t fo = p.f32_native ? nat : lin;
-                        const bool fok = p.f32_native || inside;
-                        f32x4 o = {acc[row][ct][4 * g], acc[row][ct][4 * g + 1], acc[row][ct][4 * g + 2],
-                                   acc[row][ct][4 * g + 3]};
-                        if constexpr (EPI == EPI_RESIDUAL) {
-                            if (fok) {
-                                if (p.chan_scale) o = o * *reinterpret_cast<const f32x4*>(p.chan_scale + 32 * ct + 8 * g + 4 * h);
-                                o = o * p.s1 + *reinterpret_cast<const f32x4*>(p.res1 + fo);
-                                if (p.res2) o = o * p.s2 + *reinterpret_cast<const f32x4*>(p.res2 + fo);
-                                if (p.post_act) {
+                        for (int ph = 0; ph < 2; ++ph) {
+                            const int y = y0 + RPW * wave + row;
+                            const int x = x0 + 16 * ph + q;
+                            const bool inside = y < p.H && x < p.W;
+                            const size_t pix = (size_t)y * p.W + x;
+                            const size_t nat = ((((((size_t)t * NWAVES + wave) * RPW + row) * NW + w) * 2 + ph) * 64 + lane) * 4;
+                            const size_t lin = pix * (p.f32_cstride ? p.f32_cstride : NC) + p.f32_coff + 16 * w + 4 * sl;
+                            const size_t fo = p.f32_native ? nat : lin;
+                            const bool fok = p.f32_native || inside;
+                            f32x4 o = acc[row][w][ph];
+                            if constexpr (EPI == EPI_RESIDUAL) {
+                                if (fok) {
+                                    if (p.chan_scale) o = o * *reinterpret_cast<const f32x4*>(p.chan_scale + 16 * w + 4 * sl);
+                                    o = o * p.s1 + *reinterpret_cast<const f32x4*>(p.res1 + fo);
+                                    if (p.res2) o = o * p.s2 + *reinterpret_cast<const f32x4*>(p.res2 + fo);
+                                    if (p.post_act) {
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.2f * o[j]);
+                                    }
+                                }
+                            } else {
+                                if (p.act) {
 #pragma unroll
                                     for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.2f * o[j]);
                                 }
                             }
-                        } else {
-                            if (p.act) {
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.2f * o[j]);
-                            }
+                            if (p.out_f32 && fok) *reinterpret_cast<f32x4*>(p.out_f32 + fo) = o;
+                            acc[row][w][ph] = o;
                         }
-                        if (p.out_f32 && fok) *reinterpret_cast<f32x4*>(p.out_f32 + fo) = o;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[row][ct][4 * g + j] = o[j];
-                    }
-            }
             }
             FW_STAMP(3);  // fp32-side epilogue
             // (2) typed NHWC output: transpose each row through LDS so that one wave-instruction stores whole
@@ -411,42 +355,41 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
                 // pass 0: the typed output; pass 1 (64-channel convs feeding a split trunk): lo = T(y - T(y)) into out_lo
                 const int npass = (CT == 2 && p.out_lo) ? 2 : 1;
                 for (int pass = 0; pass < npass; ++pass) {
-                T* outp = reinterpret_cast<T*>(pass ? p.out_lo : p.out);
+                    T* outp = reinterpret_cast<T*>(pass ? p.out_lo : p.out);
 #pragma unroll
-                for (int row = 0; row < RPW; ++row) {
-                    const int y = y0 + RPW * wave + row;
+                    for (int row = 0; row < RPW; ++row) {
+                        const int y = y0 + RPW * wave + row;
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
+                        for (int w = 0; w < NW; ++w)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            f32x4 o = {acc[row][ct][4 * g], acc[row][ct][4 * g + 1], acc[row][ct][4 * g + 2],
-                                       acc[row][ct][4 * g + 3]};
-                            if (pass) o = o - Op<T>::unpack4(Op<T>::pack4(o[0], o[1], o[2], o[3]));
-                            *reinterpret_cast<uint2*>(scr + r * PSTR + ct * 64 + (8 * g + 4 * h) * 2) =
-                                Op<T>::pack4(o[0], o[1], o[2], o[3]);
-                        }
-                    constexpr int LPP = 4 * CT;  // lanes per pixel (16 B each)
-                    constexpr int PPI = 64 / LPP;
+                            for (int ph = 0; ph < 2; ++ph) {
+                                f32x4 o = acc[row][w][ph];
+                                if (pass) o = o - Op<T>::unpack4(Op<T>::pack4(o[0], o[1], o[2], o[3]));
+                                *reinterpret_cast<uint2*>(scr + (16 * ph + q) * PSTR + (16 * w + 4 * sl) * 2) =
+                                    Op<T>::pack4(o[0], o[1], o[2], o[3]);
+                            }
+                        constexpr int LPP = 4 * CT;  // lanes per pixel (16 B each)
+                        constexpr int PPI = 64 / LPP;
 #pragma unroll
-                    for (int it = 0; it < 32 / PPI; ++it) {
-                        const int px = it * PPI + lane / LPP;
-                        const int q = lane % LPP;
-                        uint4 v;
-                        if constexpr (CT == 1) {
-                            v = *reinterpret_cast<const uint4*>(scr + px * PSTR + q * 16);
-                        } else {
-                            const uint2 lo = *reinterpret_cast<const uint2*>(scr + px * PSTR + q * 16);
-                            const uint2 hi = *reinterpret_cast<const uint2*>(scr + px * PSTR + q * 16 + 8);
-                            v = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                        }
-                        const int x = x0 + px;
-                        if (y < p.H && x < p.W) {
-                            T* dst = outp + ((size_t)y * p.W + x) * p.out_cstride + p.out_coff + (q >> 2) * p.out_pstride +
-                                     (q & 3) * 8;
-                            *reinterpret_cast<uint4*>(dst) = v;
+                        for (int it = 0; it < 32 / PPI; ++it) {
+                            const int px = it * PPI + lane / LPP;
+                            const int k = lane % LPP;
+                            uint4 v;
+                            if constexpr (CT == 1) {
+                                v = *reinterpret_cast<const uint4*>(scr + px * PSTR + k * 16);
+                            } else {
+                                const uint2 lo = *reinterpret_cast<const uint2*>(scr + px * PSTR + k * 16);
+                                const uint2 hi = *reinterpret_cast<const uint2*>(scr + px * PSTR + k * 16 + 8);
+                                v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                            }
+                            const int x = x0 + px;
+                            if (y < p.H && x < p.W) {
+                                T* dst = outp + ((size_t)y * p.W + x) * p.out_cstride + p.out_coff + (k >> 2) * p.out_pstride +
+                                         (k & 3) * 8;
+                                *reinterpret_cast<uint4*>(dst) = v;
+                            }
                         }
                     }
-                }
                 }
             }
             FW_STAMP(6);  // typed store through LDS
@@ -589,9 +532,9 @@ float operand_to_f32(DType dt, uint16_t v) {
     return (float)hv;
 }
 
-// Fragment order: [chunk c][tap t = ky*3+kx][ks][cout tile ct][lane][j], value =
-//   w[cout = 32*ct + (lane & 31)][cin = 32*c + 16*ks + 8*(lane >> 5) + j][ky][kx]      (zero outside)
-// which is exactly the v_mfma_f32_32x32x16 A-operand map (row = lane & 31, k = 8*(lane >> 5) + j).
+// Fragment order: [chunk c][tap t = ky*3+kx][16-channel cout tile w][lane][j], value =
+//   w[cout = 16*w + (lane & 15)][cin = 32*c + 8*(lane >> 4) + j][ky][kx]      (zero outside)
+// which is exactly the v_mfma_f32_16x16x32 A-operand map (row = lane & 15, k = 8*(lane >> 4) + j).
 size_t pack_conv3x3_weights(DType dt, const float* w, int cout, int cin, int cout_tiles, int cin_chunks,
                             uint16_t* dst) {
     const size_t n = (size_t)cin_chunks * 9 * 2 * cout_tiles * 64 * 8;
@@ -599,16 +542,15 @@ size_t pack_conv3x3_weights(DType dt, const float* w, int cout, int cin, int cou
     size_t o = 0;
     for (int c = 0; c < cin_chunks; ++c)
         for (int t = 0; t < 9; ++t)
-            for (int ks = 0; ks < 2; ++ks)
-                for (int ct = 0; ct < cout_tiles; ++ct)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 8; ++j) {
-                            const int co = 32 * ct + (lane & 31);
-                            const int ci = 32 * c + 16 * ks + 8 * (lane >> 5) + j;
-                            float val = 0.f;
-                            if (co < cout && ci < cin) val = w[((size_t)co * cin + ci) * 9 + t];
-                            dst[o++] = f32_to_operand(dt, val);
-                        }
+            for (int wt = 0; wt < 2 * cout_tiles; ++wt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = 16 * wt + (lane & 15);
+                        const int ci = 32 * c + 8 * (lane >> 4) + j;
+                        float val = 0.f;
+                        if (co < cout && ci < cin) val = w[((size_t)co * cin + ci) * 9 + t];
+                        dst[o++] = f32_to_operand(dt, val);
+                    }
     return n;
 }
 

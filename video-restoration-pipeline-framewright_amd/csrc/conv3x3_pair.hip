@@ -35,22 +35,17 @@ struct PairSmem {
     static constexpr int TOTAL = W_BASE + 2 * W_REGION;   // 152 KiB
 };
 
-struct PairFrags {
-    uint4 x[RPW + 2];
-    uint4 wa[3];
-    uint4 wb[3];
-};
-
 template <typename T>
 __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const ConvPairParams p) {
     using SM = PairSmem;
     __shared__ __attribute__((aligned(16))) uint4 lds[SM::TOTAL];
+    constexpr int NW = 4;  // accumulator tiles of 16 output channels: 0,1 = conv_a, 2,3 = conv_b
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int r = lane & 31;
-    const int h = lane >> 5;
+    const int q = lane & 15;   // pixel within a 16-pixel half row (B/D column), output channel within a tile (A row)
+    const int sl = lane >> 4;  // 8-channel slot of the chunk (A/B k index), 4-channel group of the D tile
     FW_STAMP_INIT();
 
     const int NB = gridDim.x;
@@ -68,22 +63,26 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
 
     // ---- per-lane DMA plan (as in conv3x3_mfma.hip; the compute region plays the role of the tile) ----------------------
     int rel[ACT_ITERS];
-    int rp[ACT_ITERS];
+    auto piece_pos = [&](int i, int* row, int* px) {
+        const int idx = (wave + NWAVES * i) * 64 + lane;
+        const int rw = idx / ROW_PIECES;
+        *px = (idx - rw * ROW_PIECES) >> 2;
+        *row = (idx < ACT_PIECES) ? rw : -1;
+    };
 #pragma unroll
     for (int i = 0; i < ACT_ITERS; ++i) {
         const int idx = (wave + NWAVES * i) * 64 + lane;
         const int row = idx / ROW_PIECES;
         const int rm = idx - row * ROW_PIECES;
         const int px = rm >> 2;
-        const int s = (rm & 3) ^ ((px >> 2) & 3);
+        const int s = (rm & 3) ^ halo_swz(px);
         rel[i] = ((row - 1) * p.W + (px - 1)) * p.in_cstride + s * 8;
-        rp[i] = (idx < ACT_PIECES) ? ((row << 8) | px) : -1;
     }
     const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)lds;
     const T* in = reinterpret_cast<const T*>(p.in);
     const char* wa_b = reinterpret_cast<const char*>(p.wpk_a) + lane * 16;
     const char* wb_b = reinterpret_cast<const char*>(p.wpk_b) + lane * 16;
-    const unsigned chunk_bytes = (unsigned)(p.in_pstride * 2);
+    const long chunk_bytes = p.in_pstride * 2;
 
     // compute-region origin of tile t (may be -1: the region starts one pixel outside the tile's valid outputs)
     auto origin = [&](int t, int* oy, int* ox) {
@@ -91,30 +90,37 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
         *ox = (t % tiles_x) * PAIR_TW - 1;
     };
 
-    // activation fetch stream: per tile the chunks 0..na-1, each fetched once
-    const char* src[ACT_ITERS];
-    unsigned inc[ACT_ITERS];
+    // activation fetch stream: per tile the chunks 0..na-1, each fetched once.  Per-lane state: rel[] + one bit per piece.
+    unsigned f_ok = 0;
+    const char* f_tile = nullptr;  // uniform: compute-region origin in chunk 0's plane
+    long f_coff = 0;
     int f_t = t_lo, f_c = 0;
     auto plan_tile = [&]() {
         int oy, ox;
         origin(f_t, &oy, &ox);
-        const T* base = in + ((long)oy * p.W + ox) * p.in_cstride;
+        f_tile = reinterpret_cast<const char*>(in + ((long)oy * p.W + ox) * p.in_cstride);
+        f_ok = 0;
 #pragma unroll
         for (int i = 0; i < ACT_ITERS; ++i) {
-            const int gy = oy - 1 + (rp[i] >> 8);
-            const int gx = ox - 1 + (rp[i] & 255);
-            const bool ok = rp[i] >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-            src[i] = ok ? reinterpret_cast<const char*>(base + rel[i]) : reinterpret_cast<const char*>(p.zeros);
-            inc[i] = ok ? chunk_bytes : 0u;
+            int row, px;
+            piece_pos(i, &row, &px);
+            const int gy = oy - 1 + row;
+            const int gx = ox - 1 + px;
+            if (row >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) f_ok |= 1u << i;
         }
     };
     auto issue_act_one = [&](int i, int stage) {
         if (i == 0 && f_c == 0) plan_tile();
-        glds16(src[i], lds_base + (unsigned)(stage * ACT_REGION + (wave + NWAVES * i) * 64) * 16u);
-        src[i] += inc[i];
-        if (i == ACT_ITERS - 1 && ++f_c == na) {
-            f_c = 0;
-            ++f_t;
+        const char* s = ((f_ok >> i) & 1u) ? f_tile + f_coff + (long)rel[i] * 2 : reinterpret_cast<const char*>(p.zeros);
+        glds16(s, lds_base + (unsigned)(stage * ACT_REGION + (wave + NWAVES * i) * 64) * 16u);
+        if (i == ACT_ITERS - 1) {
+            if (++f_c == na) {
+                f_c = 0;
+                f_coff = 0;
+                ++f_t;
+            } else {
+                f_coff += chunk_bytes;
+            }
         }
     };
     // weights of item j of a tile -> weight stage ws: fragments [0,18) = conv_a chunk j, [18,36) = conv_b chunk j;
@@ -128,44 +134,43 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
         }
     };
 
-    int rd_off[3][2];
+    int rd_off[3][2];  // [dx][ph]: piece index of (halo row RPW*wave, px 16*ph + q + dx, slot sl)
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            rd_off[dx][ks] = (RPW * wave) * ROW_PIECES + (r + dx) * 4 + ((2 * ks + h) ^ (((r + dx) >> 2) & 3));
-
-    auto load_group = [&](PairFrags& f, const uint4* a, const uint4* wl, int g, bool both) {
-        const int ks = g / 3, dx = g - ks * 3;
-#pragma unroll
-        for (int row = 0; row < RPW + 2; ++row) f.x[row] = a[row * ROW_PIECES + rd_off[dx][ks]];
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            if (both) f.wa[dy] = wl[((dy * 3 + dx) * 2 + ks) * 64];
-            f.wb[dy] = wl[(W_FRAGS + (dy * 3 + dx) * 2 + ks) * 64];
+        for (int ph = 0; ph < 2; ++ph) {
+            const int px = 16 * ph + q + dx;
+            rd_off[dx][ph] = (RPW * wave) * ROW_PIECES + px * 4 + (sl ^ halo_swz(px));
         }
-    };
+    // weight fragment of (tap, tile w) inside a weight stage
+    auto widx = [](int tap, int w) { return w < 2 ? tap * 2 + w : W_FRAGS + tap * 2 + (w - 2); };
 
-    f32x16 acc_a[RPW], acc_b[RPW];
+    f32x4 acc[RPW][NW][2];  // [row][tile][16-pixel half]: pixel 16*ph + q, channels 16*(w & 1) + 4*sl + j of conv w >> 1
 
-    // acc (+bias already inside) -> LeakyReLU -> typed -> tile in LDS at `xa` (halo format, zero outside the image when
-    // `zero_outside`), then the wave copies its own rows' valid interior to the global plane with 16-B/lane stores.
-    auto emit = [&](const f32x16* acc, uint4* xa, int oy, int ox, T* plane, bool zero_outside) {
+    // tiles w0, w0+1 (+bias already inside) -> LeakyReLU -> typed -> tile in LDS at `xa` (halo format, zero outside the image
+    // when `zero_outside`), then the wave copies its own rows' valid interior to the global plane with 16-B/lane stores.
+    auto emit = [&](int w0, uint4* xa, int oy, int ox, T* plane, bool zero_outside) {
 #pragma unroll
         for (int row = 0; row < RPW; ++row) {
             const int cr = RPW * wave + row;  // row inside the compute region
-            const int gy = oy + cr, gx = ox + r;
-            const bool inside = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            const int gy = oy + cr;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float o[4];
+            for (int ph = 0; ph < 2; ++ph) {
+                const int cp = 16 * ph + q;   // pixel inside the compute region
+                const int gx = ox + cp;
+                const bool inside = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = acc[row][4 * g + j];
-                    o[j] = (zero_outside && !inside) ? 0.f : fmaxf(v, 0.2f * v);
+                for (int wl2 = 0; wl2 < 2; ++wl2) {
+                    const f32x4 v = w0 ? acc[row][2 + wl2][ph] : acc[row][wl2][ph];
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (zero_outside && !inside) ? 0.f : fmaxf(v[j], 0.2f * v[j]);
+                    // channels 16*wl2 + 4*sl + j: slot 2*wl2 + (sl >> 1), bytes 8*(sl & 1)..
+                    const int hp = cp + 1;
+                    char* dst = reinterpret_cast<char*>(xa + ((cr + 1) * HALO_W + hp) * 4 + ((2 * wl2 + (sl >> 1)) ^ halo_swz(hp))) +
+                                8 * (sl & 1);
+                    *reinterpret_cast<uint2*>(dst) = Op<T>::pack4(o[0], o[1], o[2], o[3]);
                 }
-                char* dst = reinterpret_cast<char*>(xa + ((cr + 1) * HALO_W + (r + 1)) * 4 + (g ^ (((r + 1) >> 2) & 3))) + 8 * h;
-                *reinterpret_cast<uint2*>(dst) = Op<T>::pack4(o[0], o[1], o[2], o[3]);
             }
         }
         // copy-out: 64 lanes = 16 pixels x 4 physical slots; logical slot = physical ^ swizzle(px)
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
                 const int k = lane & 3;
                 const int hp = cp + 1;                  // halo-tile pixel
                 const uint4 v = xa[((cr + 1) * HALO_W + hp) * 4 + k];
-                const int s = k ^ ((hp >> 2) & 3);
+                const int s = k ^ halo_swz(hp);
                 const int gx = ox + cp;
                 if (cr >= 1 && cr <= PAIR_TH && cp >= 1 && cp <= PAIR_TW && (unsigned)gy < (unsigned)p.H &&
                     (unsigned)gx < (unsigned)p.W)
@@ -196,21 +201,19 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
 #pragma unroll
     for (int i = 0; i < ACT_ITERS; ++i) issue_act_one(i, 0);
 
-    int n = 0;   // global item counter (weight stage = n & 1)
-    int q = 0;   // DMA'd chunks consumed so far
+    int n = 0;    // global item counter (weight stage = n & 1)
+    int qd = 0;   // DMA'd chunks consumed so far
     for (int t = t_lo; t < t_hi; ++t) {
         int oy, ox;
         origin(t, &oy, &ox);
-        // accumulators start at the bias (re-read per tile: 128 B from L1/L2, cheaper than 32 live registers)
+        // accumulators start at the bias (re-read per tile: 256 B from L1/L2, cheaper than 32 live registers)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float ba = p.bias_a[(i & 3) + 8 * (i >> 2) + 4 * h];
-            const float bb = p.bias_b[(i & 3) + 8 * (i >> 2) + 4 * h];
+        for (int w = 0; w < NW; ++w) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>((w < 2 ? p.bias_a : p.bias_b) + 16 * (w & 1) + 4 * sl);
 #pragma unroll
-            for (int row = 0; row < RPW; ++row) {
-                acc_a[row][i] = ba;
-                acc_b[row][i] = bb;
-            }
+            for (int row = 0; row < RPW; ++row)
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) acc[row][w][ph] = bv;
         }
         // one pipeline item; BOTH = shared input chunk (feeds conv_a and conv_b), !BOTH = conv_b's x_a chunk
         auto run_item = [&](int j, auto both_tag) {
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
             // next DMA'd chunk: item j+1 if it is a shared chunk; during the LAST shared chunk the next tile's first
             // chunk (the x_a item needs no DMA); during the x_a item nothing (both stages are occupied)
             const bool fetch = !(FW_PAIR_DBG & 1) && BOTH && more && (j + 1 < na || t + 1 < t_hi);
-            const int fetch_stage = (q + 1) & 1;
+            const int fetch_stage = (qd + 1) & 1;
             auto dma_slot = [&](int d) {
                 if (d < SM::W_ITERS) {
                     if (more && !(FW_PAIR_DBG & 2)) issue_w_one(d, jn, (n + 1) & 1);
@@ -233,49 +236,11 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
                     if (fetch) issue_act_one(d - SM::W_ITERS, fetch_stage);
                 }
             };
-            // stage of this item: shared chunk -> q & 1; x_a item -> the stage of the last shared chunk, (q - 1) & 1
-            const uint4* a = lds + ((BOTH ? q : q - 1) & 1) * ACT_REGION;
+            // stage of this item: shared chunk -> qd & 1; x_a item -> the stage of the last shared chunk, (qd - 1) & 1
+            const uint4* a = lds + ((BOTH ? qd : qd - 1) & 1) * ACT_REGION;
             const uint4* wl = lds + SM::W_BASE + (n & 1) * SM::W_REGION + lane;
-            auto mfma_group = [&](const PairFrags& f, int gi) {
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                    for (int row = 0; row < RPW; ++row) {
-                        if constexpr (!(FW_PAIR_DBG & 8)) {
-                            if constexpr (BOTH) acc_a[row] = Op<T>::mfma(f.wa[dy], f.x[row + dy], acc_a[row]);
-                            acc_b[row] = Op<T>::mfma(f.wb[dy], f.x[row + dy], acc_b[row]);
-                        }
-                        FW_SB();
-                        dma_slot(gi * 6 + dy * 2 + row);
-                        FW_SB();
-                    }
-            };
-            PairFrags fa, fb;
-            load_group(fa, a, wl, 0, BOTH);
-            FW_SB();
-            load_group(fb, a, wl, 1, BOTH);
-            FW_SB();
-            mfma_group(fa, 0);
-            FW_SB();
-            load_group(fa, a, wl, 2, BOTH);
-            FW_SB();
-            mfma_group(fb, 1);
-            FW_SB();
-            load_group(fb, a, wl, 3, BOTH);
-            FW_SB();
-            mfma_group(fa, 2);
-            FW_SB();
-            load_group(fa, a, wl, 4, BOTH);
-            FW_SB();
-            mfma_group(fb, 3);
-            FW_SB();
-            load_group(fb, a, wl, 5, BOTH);
-            FW_SB();
-            mfma_group(fa, 4);
-            FW_SB();
-            mfma_group(fb, 5);
-            FW_SB();
-            if (BOTH) ++q;
+            conv_item<T, NW, BOTH ? 0 : 2>(acc, a, wl, rd_off, widx, dma_slot, [](const uint4 (&)[RPW][2]) {});
+            if (BOTH) ++qd;
             ++n;
         };
         FW_STAMP(4);  // tile setup (bias -> accumulators)
@@ -284,19 +249,18 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
         // conv_a done.  Every wave must be finished with the last chunk's stage before it becomes the x_a tile.
         __syncthreads();
         FW_STAMP(0);
-        if (!(FW_PAIR_DBG & 4)) emit(acc_a, lds + ((q - 1) & 1) * ACT_REGION, oy, ox, reinterpret_cast<T*>(p.out_a), true);
+        if (!(FW_PAIR_DBG & 4)) emit(0, lds + ((qd - 1) & 1) * ACT_REGION, oy, ox, reinterpret_cast<T*>(p.out_a), true);
         FW_STAMP(3);  // emit of x_a
         run_item(na, std::false_type{});
         FW_STAMP(2);  // x_a item compute
         // conv_b done: every wave has finished reading the x_a tile before it is reused as the store-transpose buffer
         __syncthreads();
         FW_STAMP(0);
-        if (!(FW_PAIR_DBG & 4)) emit(acc_b, lds + ((q - 1) & 1) * ACT_REGION, oy, ox, reinterpret_cast<T*>(p.out_b), false);
+        if (!(FW_PAIR_DBG & 4)) emit(2, lds + ((qd - 1) & 1) * ACT_REGION, oy, ox, reinterpret_cast<T*>(p.out_b), false);
         FW_STAMP(3);
     }
     FW_STAMP_FLUSH(p.stamps);
 }
-
 
 static int pair_num_cus() {
     static int n = [] {

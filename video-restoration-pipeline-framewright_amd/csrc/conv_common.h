@@ -15,18 +15,10 @@ template <typename T>
 struct Op;
 template <>
 struct Op<__bf16> {
-    static __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
-#ifdef FW_MFMA16_TIMING  // timing experiment only (wrong results): the same FLOPs as two 16x16x32 MFMAs
-        f32x4 c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
-        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c1, 0, 0, 0);
-        c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3];
-        c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
-        return c;
-#else
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
-                                                       0, 0, 0);
-#endif
+    // D(16 cout x 16 px) += A(16 cout x 32 cin) * B(32 cin x 16 px); lane l: A row / B,D column l & 15, k = 8*(l >> 4) + j
+    // (16 bytes), D rows 4*(l >> 4) + j
+    static __device__ __forceinline__ f32x4 mfma16(uint4 a, uint4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
     static __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
         bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
@@ -39,9 +31,8 @@ struct Op<__bf16> {
 };
 template <>
 struct Op<_Float16> {
-    static __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0,
-                                                      0, 0);
+    static __device__ __forceinline__ f32x4 mfma16(uint4 a, uint4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
     static __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
         f16x4 v = {(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};
@@ -66,14 +57,17 @@ constexpr int RPW = TILE_H / NWAVES;                      // output rows per wav
 constexpr int ACT_ITERS = ACT_INSTR / NWAVES;             // 5 per wave, every wave issues all of them
 constexpr int W_FRAGS = 18;                               // 9 taps x 2 k-steps of 16, per cout tile
 
-// LDS image of one activation chunk: [halo row][halo px][4 slots of 16 B]; slot s (= 8 channels) of pixel p is
-// stored at slot s ^ ((p >> 2) & 3).  A fragment read takes, for 16 lanes with distinct p mod 16, the 256-byte
-// bank row positions (p & 3) * 64 + (s ^ ((p >> 2) & 3)) * 16: all 16 distinct -> conflict free.
+// LDS image of one activation chunk: [halo row][halo px][4 slots of 16 B]; slot s (= 8 channels) of pixel p is stored
+// at slot s ^ halo_swz(p).  A B-fragment read (v_mfma_f32_16x16x32: lane l -> pixel p0 + (l & 15), slot l >> 4) puts the
+// four 16-lane groups of ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) on 16 distinct 16-byte bank positions
+// (p & 3) * 4 + (s ^ halo_swz(p)) for every p0 - the swizzle 2*((p >> 2) & 1) is the one that does (the others with
+// period <= 8 pixels were enumerated and conflict).
 // The image is filled by LDS-DMA (global_load_lds_dwordx4): the LDS destination of a wave-instruction is
 // lane-linear, so the swizzle is applied on the per-lane SOURCE address (cdna_hip_programming.md rule 21).
 // Lanes whose halo position is outside the image read a 16-byte zero page instead, so every wave issues the same
 // number of DMA instructions per stage (the counted s_waitcnt vmcnt below relies on it) and zero padding costs
 // nothing.
+__host__ __device__ constexpr int halo_swz(int px) { return ((px >> 2) & 1) << 1; }
 
 template <int CT>
 struct Smem {
@@ -101,14 +95,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
         : "v"(gsrc), "s"(lds_dst)
         : "memory");
 }
-
-// Fragments of one (k-step, dx) group: the wave's RPW+2 halo rows at column offset dx and the 3 (dy) weight
-// fragments per cout tile -> 3*RPW*CT MFMAs.
-template <int CT>
-struct Frags {
-    uint4 x[RPW + 2];
-    uint4 w[3][CT];
-};
 
 // Phase stamps (diagnostic build -DFW_PAIR_STAMP only; in the product build no stamp executes): every wave accumulates
 // s_memtime deltas per phase into 8 slots; slot 7 = the wave's lifetime in 100 MHz s_memrealtime ticks, so the clock the
@@ -146,5 +132,64 @@ unsigned long long* stamp_buffer(int which);
 #define FW_SB() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// One pipeline item: 32 input channels x 9 taps of the wave's RPW rows x 32 pixels into NW - W_LO accumulator tiles of
+// 16 output channels (x 2 pixel halves).  `a` = the activation stage, `wl` = the weight stage + lane, widx(tap, w) = the
+// fragment index of weight tile w at that tap, rd_off[dx][ph] = the lane's piece offset in halo row RPW*wave.
+// Schedule: 9 steps (dx outer, dy inner).  The weight fragments of step t+1 are read under the MFMAs of step t (register
+// double buffer).  The B fragments roll in place: rows 0/1 of the next dx are read into their registers as soon as dy = 1/2
+// has issued (their last use), rows 2/3 at the start of the next dx, one step before they are needed.  sched_barrier(0)
+// pins that order; left alone hipcc sinks every ds_read to just before its first use.
+// dma_slot(k), k = 0..35, is called after every 2*(NW - W_LO) MFMAs; on_centre(xc) once with the centre-tap B fragments
+// xc[row][ph] (the wave's own pixels).
+template <typename T, int NW, int W_LO, typename WIdx, typename Slot, typename Centre>
+__device__ __forceinline__ void conv_item(f32x4 (&acc)[RPW][NW][2], const uint4* a, const uint4* wl, const int (&rd_off)[3][2],
+                                          WIdx widx, Slot dma_slot, Centre on_centre) {
+    constexpr int NWU = NW - W_LO;
+    uint4 xr[RPW + 2][2];
+    uint4 wf[2][NWU];
+#pragma unroll
+    for (int row = 0; row < RPW + 2; ++row)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) xr[row][ph] = a[row * ROW_PIECES + rd_off[0][ph]];
+#pragma unroll
+    for (int w = 0; w < NWU; ++w) wf[0][w] = wl[widx(0, W_LO + w) * 64];
+    FW_SB();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int dx = t / 3, dy = t - 3 * dx;
+        if (t + 1 < 9) {
+            const int dx1 = (t + 1) / 3, dy1 = (t + 1) - 3 * dx1;
+#pragma unroll
+            for (int w = 0; w < NWU; ++w) wf[(t + 1) & 1][w] = wl[widx(dy1 * 3 + dx1, W_LO + w) * 64];
+        }
+        if (dx < 2 && dy >= 1) {
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) xr[dy - 1][ph] = a[(dy - 1) * ROW_PIECES + rd_off[dx + 1][ph]];
+        }
+        if (dx > 0 && dy == 0) {
+#pragma unroll
+            for (int row = 2; row < RPW + 2; ++row)
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) xr[row][ph] = a[row * ROW_PIECES + rd_off[dx][ph]];
+        }
+        FW_SB();
+#pragma unroll
+        for (int row = 0; row < RPW; ++row)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+#pragma unroll
+                for (int w = 0; w < NWU; ++w)
+                    acc[row][W_LO + w][ph] = Op<T>::mfma16(wf[t & 1][w], xr[row + dy][ph], acc[row][W_LO + w][ph]);
+                FW_SB();
+                dma_slot(t * 4 + row * 2 + ph);
+                FW_SB();
+            }
+        if (dx == 1 && dy == 1) {
+            const uint4 xc[RPW][2] = {{xr[1][0], xr[1][1]}, {xr[2][0], xr[2][1]}};
+            on_centre(xc);
+            FW_SB();
+        }
+    }
+}
 
 }  // namespace fw
