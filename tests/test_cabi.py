@@ -47,16 +47,16 @@ def _pack_ref(w, dtype, cout_tiles, cin_chunks):
     wp[:cout, :cin] = w
     t = torch.from_numpy(wp).to(torch.bfloat16 if dtype == _lib.FW_DTYPE_BF16 else torch.float16)
     bits = t.view(torch.int16).numpy().view(np.uint16)
-    out = np.empty((cin_chunks, 9, 2, cout_tiles, 64, 8), np.uint16)
+    # [chunk][tap][16-channel cout tile][lane][j]: v_mfma_f32_16x16x32 A operand, row = lane & 15, k = 8*(lane >> 4) + j
+    out = np.empty((cin_chunks, 9, 2 * cout_tiles, 64, 8), np.uint16)
     lane = np.arange(64)
     for c in range(cin_chunks):
         for tap in range(9):
-            for ks in range(2):
-                for ct in range(cout_tiles):
-                    co = 32 * ct + (lane & 31)
-                    for j in range(8):
-                        ci = 32 * c + 16 * ks + 8 * (lane >> 5) + j
-                        out[c, tap, ks, ct, :, j] = bits[co, ci, tap // 3, tap % 3]
+            for wt in range(2 * cout_tiles):
+                co = 16 * wt + (lane & 15)
+                for j in range(8):
+                    ci = 32 * c + 8 * (lane >> 4) + j
+                    out[c, tap, wt, :, j] = bits[co, ci, tap // 3, tap % 3]
     return out.reshape(-1)
 
 
