@@ -213,9 +213,9 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
             // item n has landed (each wave waits for its own DMAs, then the barrier) and every wave is done reading
             // the stages that are refilled during this item
             if (NA == 3 && n + 1 < nitems)
-                asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // ACT_ITERS: activations(n+1) may stay in flight
+                FW_WAIT_VMCNT(5);  // ACT_ITERS: activations(n+1) may stay in flight
             else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                FW_WAIT_VMCNT(0);
             FW_STAMP(5);  // this wave's own DMAs
             __syncthreads();
             FW_STAMP(0);  // barrier
@@ -247,9 +247,10 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
 #pragma unroll
                         for (int ph = 0; ph < 2; ++ph) {
                             const int y = y0 + RPW * wave + row, x = x0 + 16 * ph + q;
-                            const bool inside = y < p.H && x < p.W;
-                            const char* px = plane + (((size_t)y * p.W + x) * p.in_cstride + 8 * sl) * 2;
-                            idx[row][ph] = inside ? *reinterpret_cast<const uint4*>(px) : make_uint4(0, 0, 0, 0);
+                            // outside the image: the zero page (a select on the loaded VALUE would wait for the load here)
+                            const char* px = (y < p.H && x < p.W) ? plane + (((size_t)y * p.W + x) * p.in_cstride + 8 * sl) * 2
+                                                                  : reinterpret_cast<const char*>(p.zeros);
+                            idx[row][ph] = *reinterpret_cast<const uint4*>(px);
                         }
                 }
             }
@@ -261,10 +262,11 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
                         if (c < CT && p.in_id_scale != 0.f) add_identity(xc, p.in_id_scale, c);
                     }
                 });
+            FW_STAMP(1);  // item compute
             if constexpr (SPLIT) {
                 if (has_id) add_identity(idx, p.id_scale[c], c & 1);
             }
-            FW_STAMP(1);  // item compute
+            FW_STAMP(2);  // residual plane: wait for its loads + 8 identity MFMAs
         }
 
         // ---- epilogue (the DMA stream is already fetching the next tile) -----------------------------------------

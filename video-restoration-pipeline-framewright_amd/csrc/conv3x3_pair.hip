@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
         auto run_item = [&](int j, auto both_tag) {
             constexpr bool BOTH = decltype(both_tag)::value;
             FW_STAMP(BOTH ? 1 : 2);   // previous phase ends (compute of the previous item / emit)
-            if (!(FW_PAIR_DBG & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(FW_PAIR_DBG & 32)) FW_WAIT_VMCNT(0);
             FW_STAMP(5);              // waiting for this wave's own DMAs
             if (!(FW_PAIR_DBG & 16)) __syncthreads();
             FW_STAMP(0);              // barrier

@@ -126,6 +126,15 @@ unsigned long long* stamp_buffer(int which);
 #define FW_STAMP_FLUSH(buf) do { } while (0)
 #endif
 
+// Counted wait on the vector-memory counter as a BUILTIN (simm16: vmcnt | expcnt 7 << 4 | lgkmcnt 15 << 8), not inline asm:
+// hipcc's waitcnt pass then knows that its own loads (bias, residual planes) have landed and does not wait for them again
+// together with whatever was issued after them.  The LDS-DMAs themselves stay invisible to it (glds16).
+#define FW_WAIT_VMCNT(n)                                   \
+    do {                                                   \
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (n));          \
+        asm volatile("" ::: "memory");                     \
+    } while (0)
+
 #ifdef FW_NO_SB
 #define FW_SB()
 #else
@@ -135,33 +144,35 @@ unsigned long long* stamp_buffer(int which);
 // One pipeline item: 32 input channels x 9 taps of the wave's RPW rows x 32 pixels into NW - W_LO accumulator tiles of
 // 16 output channels (x 2 pixel halves).  `a` = the activation stage, `wl` = the weight stage + lane, widx(tap, w) = the
 // fragment index of weight tile w at that tap, rd_off[dx][ph] = the lane's piece offset in halo row RPW*wave.
-// Schedule: 9 steps (dx outer, dy inner).  The weight fragments of step t+1 are read under the MFMAs of step t (register
-// double buffer).  The B fragments roll in place: rows 0/1 of the next dx are read into their registers as soon as dy = 1/2
-// has issued (their last use), rows 2/3 at the start of the next dx, one step before they are needed.  sched_barrier(0)
-// pins that order; left alone hipcc sinks every ds_read to just before its first use.
+// Schedule: 9 steps (dx outer, dy inner) x (NW - W_LO) weight tiles, 4 MFMAs (RPW rows x 2 pixel halves) per weight tile.
+// Weight fragments run through a 3-deep register ring, read two tiles ahead.  The B fragments roll in place: rows 0/1 of
+// the next dx are read into their registers as soon as dy = 1/2 has issued (their last use), rows 2/3 at the start of the
+// next dx, one step before they are needed.  sched_barrier(0) pins that order; left alone hipcc sinks every ds_read to just
+// before its first use.
 // dma_slot(k), k = 0..35, is called after every 2*(NW - W_LO) MFMAs; on_centre(xc) once with the centre-tap B fragments
 // xc[row][ph] (the wave's own pixels).
 template <typename T, int NW, int W_LO, typename WIdx, typename Slot, typename Centre>
 __device__ __forceinline__ void conv_item(f32x4 (&acc)[RPW][NW][2], const uint4* a, const uint4* wl, const int (&rd_off)[3][2],
                                           WIdx widx, Slot dma_slot, Centre on_centre) {
     constexpr int NWU = NW - W_LO;
+    constexpr int NK = 9 * NWU;  // weight fragments of the item, in use order
     uint4 xr[RPW + 2][2];
-    uint4 wf[2][NWU];
+    uint4 wf[3];
+    auto load_w = [&](int k) {
+        const int t = k / NWU, w = k - t * NWU;
+        const int dx = t / 3, dy = t - 3 * dx;
+        wf[k % 3] = wl[widx(dy * 3 + dx, W_LO + w) * 64];
+    };
 #pragma unroll
     for (int row = 0; row < RPW + 2; ++row)
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) xr[row][ph] = a[row * ROW_PIECES + rd_off[0][ph]];
-#pragma unroll
-    for (int w = 0; w < NWU; ++w) wf[0][w] = wl[widx(0, W_LO + w) * 64];
+    load_w(0);
+    load_w(1);
     FW_SB();
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int dx = t / 3, dy = t - 3 * dx;
-        if (t + 1 < 9) {
-            const int dx1 = (t + 1) / 3, dy1 = (t + 1) - 3 * dx1;
-#pragma unroll
-            for (int w = 0; w < NWU; ++w) wf[(t + 1) & 1][w] = wl[widx(dy1 * 3 + dx1, W_LO + w) * 64];
-        }
         if (dx < 2 && dy >= 1) {
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) xr[dy - 1][ph] = a[(dy - 1) * ROW_PIECES + rd_off[dx + 1][ph]];
@@ -172,18 +183,22 @@ __device__ __forceinline__ void conv_item(f32x4 (&acc)[RPW][NW][2], const uint4*
 #pragma unroll
                 for (int ph = 0; ph < 2; ++ph) xr[row][ph] = a[row * ROW_PIECES + rd_off[dx][ph]];
         }
-        FW_SB();
 #pragma unroll
-        for (int row = 0; row < RPW; ++row)
+        for (int w = 0; w < NWU; ++w) {
+            const int k = t * NWU + w;
+            if (k + 2 < NK) load_w(k + 2);
+            FW_SB();
 #pragma unroll
-            for (int ph = 0; ph < 2; ++ph) {
+            for (int row = 0; row < RPW; ++row)
 #pragma unroll
-                for (int w = 0; w < NWU; ++w)
-                    acc[row][W_LO + w][ph] = Op<T>::mfma16(wf[t & 1][w], xr[row + dy][ph], acc[row][W_LO + w][ph]);
-                FW_SB();
-                dma_slot(t * 4 + row * 2 + ph);
-                FW_SB();
-            }
+                for (int ph = 0; ph < 2; ++ph)
+                    acc[row][W_LO + w][ph] = Op<T>::mfma16(wf[k % 3], xr[row + dy][ph], acc[row][W_LO + w][ph]);
+            FW_SB();
+            // 36 slots per item: NWU = 4 -> one per weight tile; NWU = 2 -> two per weight tile
+#pragma unroll
+            for (int d = 0; d < 4 / NWU; ++d) dma_slot((t * NWU + w) * (4 / NWU) + d);
+            FW_SB();
+        }
         if (dx == 1 && dy == 1) {
             const uint4 xc[RPW][2] = {{xr[1][0], xr[1][1]}, {xr[2][0], xr[2][1]}};
             on_centre(xc);
