@@ -41,6 +41,9 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
     const int sl = lane >> 4;  // 8-channel slot of the 32-channel chunk (A/B k index), 4-channel group of the D tile
     constexpr bool SPLIT = EPI == EPI_RESIDUAL_SPLIT;
     FW_STAMP_INIT();
+#ifdef FW_SETPRIO
+    if (wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(FW_SETPRIO);
+#endif
 
     // ---- persistent workgroup: a contiguous range of tiles ---------------------------------------------------
     // Blocks b and b+8 share an XCD (and its L2): logical id lb puts the blocks of one XCD on a contiguous band of
@@ -58,44 +61,48 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
     const int nitems = (t_hi - t_lo) * nch;  // (tile, chunk) pairs, walked as one pipelined sequence
 
     // ---- per-lane DMA plan ------------------------------------------------------------------------------------
+    // Piece i of this lane = 16 bytes of halo position (row, px), slot s; a wave owns ACT_ITERS consecutive KiB of the stage
+    // so that its pieces go out as one batch (one M0, conv_common.h).  The source of a piece is the wave-uniform address of
+    // the tile's halo origin (row 0, px 0 = one pixel up-left of the tile) in the chunk's plane plus the loop-constant byte
+    // offset; pieces outside the image read the zero page through a per-lane address (border tiles only).
     const int ups = p.upsample2x;
     const int Ws = ups ? (p.W >> 1) : p.W;
-    int rel[ACT_ITERS];  // element offset of this lane's piece from the tile origin (may be negative)
-    // halo position (row, px) of piece i of this lane; row = -1 for the pad pieces behind the 18x34 image
+    unsigned relb[ACT_ITERS];  // byte offset from the halo origin, plus (4 - i) KiB: the batch's immediate takes that off again
     auto piece_pos = [&](int i, int* row, int* px) {
-        const int idx = (wave + NWAVES * i) * 64 + lane;
+        const int idx = (ACT_ITERS * wave + i) * 64 + lane;
         const int rw = idx / ROW_PIECES;
         *px = (idx - rw * ROW_PIECES) >> 2;
-        *row = (idx < ACT_PIECES) ? rw : -1;
+        *row = (idx < ACT_PIECES) ? rw : -1;  // -1: the pad pieces behind the 18x34 image
     };
 #pragma unroll
     for (int i = 0; i < ACT_ITERS; ++i) {
-        const int idx = (wave + NWAVES * i) * 64 + lane;
+        const int idx = (ACT_ITERS * wave + i) * 64 + lane;
         const int row = idx / ROW_PIECES;
         const int rm = idx - row * ROW_PIECES;
         const int px = rm >> 2;
         const int s = (rm & 3) ^ halo_swz(px);  // which 8-channel slot lands at this LDS position
-        const int srow = ups ? ((row - 1) >> 1) : (row - 1);
-        const int spx = ups ? ((px - 1) >> 1) : (px - 1);
-        rel[i] = (srow * Ws + spx) * p.in_cstride + s * 8;
+        // nearest-x2 input reads source pixel (y >> 1, x >> 1); ((row - 1) >> 1) + 1 >= 0 for row >= 0
+        const int srow = ups ? (((row - 1) >> 1) + 1) : row;
+        const int spx = ups ? (((px - 1) >> 1) + 1) : px;
+        relb[i] = (unsigned)(((srow * Ws + spx) * p.in_cstride + s * 8) * 2) + (unsigned)(4 - i) * 1024u;
     }
     const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)lds;
-    const T* in = reinterpret_cast<const T*>(p.in);
-    const char* w_b = reinterpret_cast<const char*>(p.wpk) + lane * 16;
+    const char* in = reinterpret_cast<const char*>(p.in);
+    const char* w_b = reinterpret_cast<const char*>(p.wpk);
+    const unsigned lane16 = lane * 16;
     const long chunk_bytes = p.in_pstride * 2;
 
     // The activation DMA stream runs NA-1 items ahead of the compute and walks (tile, chunk) in order: a_t/a_c is the item
-    // it issues next.  Per-lane state is rel[] plus one bit per piece (in the image / zero page), rebuilt per tile; the
-    // source of a piece is the wave-uniform plane address of (tile origin, chunk) plus rel[].
-    unsigned a_ok = 0;
-    const char* a_tile = nullptr;  // uniform: tile origin in chunk 0's plane
-    long a_coff = 0;               // uniform: byte offset of chunk a_c's plane from chunk 0's
+    // it issues next.
+    unsigned a_ok = 0;             // bit i: piece i of this lane is inside the image
+    bool a_all = true;             // uniform: every piece of every lane of this wave is
+    const char* a_src = nullptr;   // uniform: halo origin of (tile a_t, chunk a_c)
     int a_n = 0, a_t = t_lo, a_c = 0;
     auto plan_tile = [&]() {
         const int ty0 = (a_t / tiles_x) * TILE_H, tx0 = (a_t % tiles_x) * TILE_W;
         const int sy0 = ups ? (ty0 >> 1) : ty0;
         const int sx0 = ups ? (tx0 >> 1) : tx0;
-        a_tile = reinterpret_cast<const char*>(in + ((long)sy0 * Ws + sx0) * p.in_cstride);
+        a_src = in + ((long)(sy0 - 1) * Ws + (sx0 - 1)) * p.in_cstride * 2;
         a_ok = 0;
 #pragma unroll
         for (int i = 0; i < ACT_ITERS; ++i) {
@@ -105,30 +112,42 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
             const int gx = tx0 - 1 + px;
             if (row >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) a_ok |= 1u << i;
         }
+        a_all = __builtin_amdgcn_readfirstlane(__all(a_ok == (1u << ACT_ITERS) - 1u)) != 0;
     };
-    // DMA number i (0..ACT_ITERS-1) of the next activation item
-    auto issue_act_one = [&](int i) {
-        if (i == 0 && a_c == 0) plan_tile();
-        const char* s = ((a_ok >> i) & 1u) ? a_tile + a_coff + (long)rel[i] * 2 : reinterpret_cast<const char*>(p.zeros);
-        glds16(s, lds_base + (unsigned)((a_n % NA) * ACT_REGION + (wave + NWAVES * i) * 64) * 16u);
-        if (i == ACT_ITERS - 1) {
-            ++a_n;
-            if (++a_c == nch) {
-                a_c = 0;
-                a_coff = 0;
-                ++a_t;
-            } else {
-                a_coff += chunk_bytes;
-            }
+    // the ACT_ITERS pieces of the next activation item
+    auto issue_act = [&]() {
+        if (a_c == 0) plan_tile();
+        const unsigned dst = (unsigned)((a_n % NA) * ACT_REGION + ACT_ITERS * wave * 64);  // the wave's first piece
+        if (a_all) {
+            glds16_batch_a(a_src, relb, lds_base + (dst + 4 * 64) * 16u);
+        } else {
+#pragma unroll
+            for (int i = 0; i < ACT_ITERS; ++i)
+                glds16_v(((a_ok >> i) & 1u) ? a_src + (relb[i] - (unsigned)(4 - i) * 1024u) : reinterpret_cast<const char*>(p.zeros),
+                         lds_base + (dst + i * 64) * 16u);
+        }
+        ++a_n;
+        if (++a_c == nch) {
+            a_c = 0;
+            ++a_t;
+        } else {
+            a_src += chunk_bytes;
         }
     };
-    // DMA number i (0..W_ITERS-1) of the weights of chunk c into weight stage ws.  Waves issue a different number of
-    // these (18*CT fragments over 8 waves); that is fine because they are OLDER than the counted activation DMAs.
-    auto issue_w_one = [&](int i, int c, int ws) {
-        const int f = wave + NWAVES * i;
-        if (f < W_FRAGS * CT)
-            glds16(w_b + (size_t)c * (W_FRAGS * CT * 1024) + f * 1024,
-                   lds_base + (unsigned)(SM::W_BASE + ws * SM::W_REGION + f * 64) * 16u);
+    // The weight fragments of chunk c into weight stage ws: the 18 fragments of each 32-output-channel half go to four waves
+    // (5, 5, 5, 3), waves 0-3 the first half, waves 4-7 the second (CT == 2).  They are OLDER than the activation pieces
+    // issued after them, which is what the counted vmcnt of the 3-stage pipeline relies on.
+    auto issue_w = [&](int c, int ws) {
+        const int half = wave >> 2, k = wave & 3;
+        if (half < CT) {
+            const int f4 = W_FRAGS * half + 5 * k + 4;  // the batch's fifth fragment
+            const char* src = w_b + (size_t)c * (W_FRAGS * CT * 1024) + f4 * 1024;
+            const unsigned dst = lds_base + (unsigned)(SM::W_BASE + ws * SM::W_REGION + f4 * 64) * 16u;
+            if (k < 3)
+                glds16_batch_w<5>(src, lane16, dst);
+            else
+                glds16_batch_w<3>(src, lane16, dst);
+        }
     };
 
     // ---- fragment-read plan ------------------------------------------------------------------------------------
@@ -180,14 +199,9 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
     // ---- pipeline prologue ------------------------------------------------------------------------------------
     // Issue order per boundary is [weights(n+1), activations(n+NA-1)]; vmcnt retires in order, so at boundary n
     // "all but the youngest ACT_ITERS DMAs" == everything up to and including weights(n) and activations(n).
-#pragma unroll
-    for (int i = 0; i < SM::W_ITERS; ++i) issue_w_one(i, 0, 0);
-#pragma unroll
-    for (int i = 0; i < ACT_ITERS; ++i) issue_act_one(i);
-    if (NA == 3 && nitems > 1) {
-#pragma unroll
-        for (int i = 0; i < ACT_ITERS; ++i) issue_act_one(i);
-    }
+    issue_w(0, 0);
+    issue_act();
+    if (NA == 3 && nitems > 1) issue_act();
 
     // timing ablations: build with -DFW_CONV_DEBUG=<bits> (2 = no LDS-DMA, 4 = no epilogue)
 #ifndef FW_CONV_DEBUG
@@ -222,13 +236,17 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
             const bool do_w = n + 1 < nitems && !(dbg & 2);
             const bool do_a = n + NA - 1 < nitems && !(dbg & 2);
             const int c1 = (c + 1 == nch) ? 0 : c + 1;
-            // The W_ITERS + ACT_ITERS DMAs of this boundary are issued one at a time in the shadow of the MFMAs: slot d,
-            // compile-time after unrolling.
+            // The two DMA batches of this boundary (weights of item n+1, activations of item n+NA-1) go out in the shadow
+            // of the first MFMAs: slot d of 36, compile-time after unrolling.
+#ifndef FW_DMA_SLOT_W
+#define FW_DMA_SLOT_W 0
+#define FW_DMA_SLOT_A 2
+#endif
             auto dma_slot = [&](int d) {
-                if (d < SM::W_ITERS) {
-                    if (do_w) issue_w_one(d, c1, (n + 1) & 1);
-                } else if (d - SM::W_ITERS < ACT_ITERS) {
-                    if (do_a) issue_act_one(d - SM::W_ITERS);
+                if (d == FW_DMA_SLOT_W) {
+                    if (do_w) issue_w(c1, (n + 1) & 1);
+                } else if (d == FW_DMA_SLOT_A) {
+                    if (do_a) issue_act();
                 }
             };
 
@@ -254,14 +272,16 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
                         }
                 }
             }
+            auto& slot_fn = dma_slot;
             conv_item<T, NW, 0>(
-                acc, a, wl, rd_off, [](int tap, int w) { return tap * NW + w; }, dma_slot,
+                acc, a, wl, rd_off, [](int tap, int w) { return tap * NW + w; }, slot_fn,
                 [&](const uint4 (&xc)[RPW][2]) {
                     if constexpr (SPLIT) {
                         // the conv's own input channels [32c, 32c+32) are a residual too: centre tap of the tile in LDS
                         if (c < CT && p.in_id_scale != 0.f) add_identity(xc, p.in_id_scale, c);
                     }
-                });
+                },
+                [](int) {});
             FW_STAMP(1);  // item compute
             if constexpr (SPLIT) {
                 if (has_id) add_identity(idx, p.id_scale[c], c & 1);
@@ -419,7 +439,7 @@ extern "C" int fw_debug_stamps(int which, unsigned long long* out) {
 }
 #endif
 
-static_assert(ACT_ITERS == 5, "the counted s_waitcnt vmcnt(5) in the kernel assumes 5 activation DMAs per wave");
+static_assert(ACT_ITERS == 5, "the counted s_waitcnt vmcnt(5) and the 5-piece DMA batch assume 5 activation pieces per wave");
 
 // 256 bytes of zeros per device: the DMA source of halo positions outside the image.
 static const void* zero_page() {

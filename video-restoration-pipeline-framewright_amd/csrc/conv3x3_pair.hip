@@ -47,6 +47,9 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
     const int q = lane & 15;   // pixel within a 16-pixel half row (B/D column), output channel within a tile (A row)
     const int sl = lane >> 4;  // 8-channel slot of the chunk (A/B k index), 4-channel group of the D tile
     FW_STAMP_INIT();
+#ifdef FW_SETPRIO
+    if (wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(FW_SETPRIO);
+#endif
 
     const int NB = gridDim.x;
     const int xcd = blockIdx.x & 7;
@@ -62,26 +65,27 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
     const int nitems = (t_hi - t_lo) * ipt;
 
     // ---- per-lane DMA plan (as in conv3x3_mfma.hip; the compute region plays the role of the tile) ----------------------
-    int rel[ACT_ITERS];
+    unsigned relb[ACT_ITERS];  // byte offset of this lane's piece from the region's halo origin, plus (4 - i) KiB (batch immediate)
     auto piece_pos = [&](int i, int* row, int* px) {
-        const int idx = (wave + NWAVES * i) * 64 + lane;
+        const int idx = (ACT_ITERS * wave + i) * 64 + lane;
         const int rw = idx / ROW_PIECES;
         *px = (idx - rw * ROW_PIECES) >> 2;
         *row = (idx < ACT_PIECES) ? rw : -1;
     };
 #pragma unroll
     for (int i = 0; i < ACT_ITERS; ++i) {
-        const int idx = (wave + NWAVES * i) * 64 + lane;
+        const int idx = (ACT_ITERS * wave + i) * 64 + lane;
         const int row = idx / ROW_PIECES;
         const int rm = idx - row * ROW_PIECES;
         const int px = rm >> 2;
         const int s = (rm & 3) ^ halo_swz(px);
-        rel[i] = ((row - 1) * p.W + (px - 1)) * p.in_cstride + s * 8;
+        relb[i] = (unsigned)(((row * p.W + px) * p.in_cstride + s * 8) * 2) + (unsigned)(4 - i) * 1024u;
     }
     const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)lds;
-    const T* in = reinterpret_cast<const T*>(p.in);
-    const char* wa_b = reinterpret_cast<const char*>(p.wpk_a) + lane * 16;
-    const char* wb_b = reinterpret_cast<const char*>(p.wpk_b) + lane * 16;
+    const char* in = reinterpret_cast<const char*>(p.in);
+    const char* wa_b = reinterpret_cast<const char*>(p.wpk_a);
+    const char* wb_b = reinterpret_cast<const char*>(p.wpk_b);
+    const unsigned lane16 = lane * 16;
     const long chunk_bytes = p.in_pstride * 2;
 
     // compute-region origin of tile t (may be -1: the region starts one pixel outside the tile's valid outputs)
@@ -90,15 +94,16 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
         *ox = (t % tiles_x) * PAIR_TW - 1;
     };
 
-    // activation fetch stream: per tile the chunks 0..na-1, each fetched once.  Per-lane state: rel[] + one bit per piece.
+    // activation fetch stream: per tile the chunks 0..na-1, each fetched once, as one batch of ACT_ITERS pieces per wave.
+    // Pieces outside the image read the zero page through a per-lane address (border tiles only).
     unsigned f_ok = 0;
-    const char* f_tile = nullptr;  // uniform: compute-region origin in chunk 0's plane
-    long f_coff = 0;
+    bool f_all = true;             // uniform
+    const char* f_src = nullptr;   // uniform: halo origin of (tile f_t, chunk f_c)
     int f_t = t_lo, f_c = 0;
     auto plan_tile = [&]() {
         int oy, ox;
         origin(f_t, &oy, &ox);
-        f_tile = reinterpret_cast<const char*>(in + ((long)oy * p.W + ox) * p.in_cstride);
+        f_src = in + ((long)(oy - 1) * p.W + (ox - 1)) * p.in_cstride * 2;
         f_ok = 0;
 #pragma unroll
         for (int i = 0; i < ACT_ITERS; ++i) {
@@ -108,29 +113,38 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
             const int gx = ox - 1 + px;
             if (row >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) f_ok |= 1u << i;
         }
+        f_all = __builtin_amdgcn_readfirstlane(__all(f_ok == (1u << ACT_ITERS) - 1u)) != 0;
     };
-    auto issue_act_one = [&](int i, int stage) {
-        if (i == 0 && f_c == 0) plan_tile();
-        const char* s = ((f_ok >> i) & 1u) ? f_tile + f_coff + (long)rel[i] * 2 : reinterpret_cast<const char*>(p.zeros);
-        glds16(s, lds_base + (unsigned)(stage * ACT_REGION + (wave + NWAVES * i) * 64) * 16u);
-        if (i == ACT_ITERS - 1) {
-            if (++f_c == na) {
-                f_c = 0;
-                f_coff = 0;
-                ++f_t;
-            } else {
-                f_coff += chunk_bytes;
-            }
+    auto issue_act = [&](int stage) {
+        if (f_c == 0) plan_tile();
+        const unsigned dst = (unsigned)(stage * ACT_REGION + ACT_ITERS * wave * 64);  // the wave's first piece
+        if (f_all) {
+            glds16_batch_a(f_src, relb, lds_base + (dst + 4 * 64) * 16u);
+        } else {
+#pragma unroll
+            for (int i = 0; i < ACT_ITERS; ++i)
+                glds16_v(((f_ok >> i) & 1u) ? f_src + (relb[i] - (unsigned)(4 - i) * 1024u) : reinterpret_cast<const char*>(p.zeros),
+                         lds_base + (dst + i * 64) * 16u);
+        }
+        if (++f_c == na) {
+            f_c = 0;
+            ++f_t;
+        } else {
+            f_src += chunk_bytes;
         }
     };
-    // weights of item j of a tile -> weight stage ws: fragments [0,18) = conv_a chunk j, [18,36) = conv_b chunk j;
-    // the last item (j == na) only has conv_b's chunk
-    auto issue_w_one = [&](int i, int j, int ws) {
-        const int f = wave + NWAVES * i;
-        if (f < 2 * W_FRAGS && (j < na || f >= W_FRAGS)) {
-            const char* w = f < W_FRAGS ? wa_b + (size_t)j * (W_FRAGS * 1024) + f * 1024
-                                        : wb_b + (size_t)j * (W_FRAGS * 1024) + (f - W_FRAGS) * 1024;
-            glds16(w, lds_base + (unsigned)(SM::W_BASE + ws * SM::W_REGION + f * 64) * 16u);
+    // weights of item j of a tile -> weight stage ws: fragments [0,18) = conv_a chunk j (waves 0-3: 5, 5, 5, 3 fragments),
+    // [18,36) = conv_b chunk j (waves 4-7); the last item (j == na) only has conv_b's chunk
+    auto issue_w = [&](int j, int ws) {
+        const int half = wave >> 2, k = wave & 3;
+        if (half == 1 || j < na) {
+            const int f4 = 5 * k + 4;  // the batch's fifth fragment within its half
+            const char* src = (half ? wb_b : wa_b) + (size_t)j * (W_FRAGS * 1024) + f4 * 1024;
+            const unsigned dst = lds_base + (unsigned)(SM::W_BASE + ws * SM::W_REGION + (W_FRAGS * half + f4) * 64) * 16u;
+            if (k < 3)
+                glds16_batch_w<5>(src, lane16, dst);
+            else
+                glds16_batch_w<3>(src, lane16, dst);
         }
     };
 
@@ -196,10 +210,8 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
     // ---- pipeline: one item of look-ahead.  Activation stage of DMA item q (q-th fetched chunk) = q & 1; the x_a item of a
     //      tile uses the stage of the tile's last shared chunk (free again after a barrier), while the other stage already
     //      receives the next tile's first chunk. -----------------------------------------------------------------------------
-#pragma unroll
-    for (int i = 0; i < SM::W_ITERS; ++i) issue_w_one(i, 0, 0);
-#pragma unroll
-    for (int i = 0; i < ACT_ITERS; ++i) issue_act_one(i, 0);
+    issue_w(0, 0);
+    issue_act(0);
 
     int n = 0;    // global item counter (weight stage = n & 1)
     int qd = 0;   // DMA'd chunks consumed so far
@@ -229,17 +241,28 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
             // chunk (the x_a item needs no DMA); during the x_a item nothing (both stages are occupied)
             const bool fetch = !(FW_PAIR_DBG & 1) && BOTH && more && (j + 1 < na || t + 1 < t_hi);
             const int fetch_stage = (qd + 1) & 1;
+#ifndef FW_DMA_SLOT_W
+#define FW_DMA_SLOT_W 0
+#define FW_DMA_SLOT_A 2
+#endif
             auto dma_slot = [&](int d) {
-                if (d < SM::W_ITERS) {
-                    if (more && !(FW_PAIR_DBG & 2)) issue_w_one(d, jn, (n + 1) & 1);
-                } else if (d - SM::W_ITERS < ACT_ITERS) {
-                    if (fetch) issue_act_one(d - SM::W_ITERS, fetch_stage);
+                if (d == FW_DMA_SLOT_W) {
+                    if (more && !(FW_PAIR_DBG & 2)) issue_w(jn, (n + 1) & 1);
+                } else if (d == FW_DMA_SLOT_A) {
+                    if (fetch) issue_act(fetch_stage);
                 }
             };
             // stage of this item: shared chunk -> qd & 1; x_a item -> the stage of the last shared chunk, (qd - 1) & 1
             const uint4* a = lds + ((BOTH ? qd : qd - 1) & 1) * ACT_REGION;
             const uint4* wl = lds + SM::W_BASE + (n & 1) * SM::W_REGION + lane;
-            conv_item<T, NW, BOTH ? 0 : 2>(acc, a, wl, rd_off, widx, dma_slot, [](const uint4 (&)[RPW][2]) {});
+            auto& slot_fn = dma_slot;
+            conv_item<T, NW, BOTH ? 0 : 2>(acc, a, wl, rd_off, widx, slot_fn, [](const uint4 (&)[RPW][2]) {}, [&](int step) {
+#ifdef FW_STEP_STAMPS  // BOTH items: slot 1 = steps 0-2 (the DMA slots), 6 = steps 3-5, 4 = steps 6-8
+                if (BOTH && step == 2) FW_STAMP(1);
+                if (BOTH && step == 5) FW_STAMP(6);
+                if (BOTH && step == 8) FW_STAMP(4);
+#endif
+            });
             if (BOTH) ++qd;
             ++n;
         };

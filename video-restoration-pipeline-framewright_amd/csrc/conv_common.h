@@ -80,13 +80,94 @@ struct Smem {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-// One global_load_lds_dwordx4: every lane copies 16 bytes from its own global address to LDS[lds_dst + 16 * lane];
-// lds_dst is wave-uniform.  Inline asm so that hipcc does not count these loads: with the builtin it drains them
-// (s_waitcnt vmcnt(0)) before the first ds_read of the chunk being computed, which serialises the pipeline
-// (cdna_hip_programming.md §5 "Three .s-level traps" (b)).  The matching waits are the explicit counted vmcnt at
-// the top of the chunk loop.  M0 is written inside the statement; nothing else in this kernel uses M0.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);  // wave-uniform by construction; make it provably so (SGPR operand)
+// One global_load_lds_dwordx4: every active lane copies 16 bytes from sbase + voff (wave-uniform 64-bit base in an SGPR
+// pair, 32-bit unsigned per-lane byte offset) to LDS[lds_dst + 16 * lane]; lds_dst is wave-uniform.  The SGPR-base form
+// keeps the issuing wave's VALU out of it: the per-lane offsets are loop constants and the base moves with scalar adds.
+// Inline asm so that hipcc does not count these loads: with the builtin it drains them (s_waitcnt vmcnt(0)) before the
+// first ds_read of the chunk being computed, which serialises the pipeline (cdna_hip_programming.md §5 "Three .s-level
+// traps" (b)).  The matching waits are the explicit counted vmcnt at the top of the chunk loop.  M0 is written inside the
+// statement; nothing else in these kernels uses M0.  Inactive lanes (EXEC) neither load nor write LDS.
+__device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned lds_dst) {
+    // wave-uniform by construction; readfirstlane makes it provably so where the compiler has lost track (SGPR operands)
+    const unsigned long long b = (unsigned long long)sbase;
+    // (the builtin returns int: without the casts the low half would be sign-extended over the high half)
+    const unsigned long long sb = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) << 32) |
+                                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)b);
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    // s_nop 4: an SGPR written by v_readfirstlane must not be read as the base of a global_* for 5 wait states, and
+    // nothing inside an asm statement is padded by hipcc
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1"
+        :
+        : "v"(voff), "s"(sb), "s"(lds_dst)
+        : "memory");
+}
+
+// Batches: ONE M0 write for up to five pieces of a wave.  The instruction's 13-bit signed immediate offset is added to the
+// global address AND to the LDS address (checked on gfx950: test_conv3x3_gpu passes with pieces told apart only by it), so
+// pieces whose LDS images are 1 KiB apart share an M0 that points at the fifth piece: piece i sits at offset (i - 4) KiB.
+// Rewriting M0 between LDS-DMAs is what made each of them cost the issuing wave 200-400 cycles (phase stamps, DESIGN.md
+// §6); a batch costs about one.
+// Same per-lane offset for every piece (weights: the source is as linear as the LDS image).
+template <int N>
+__device__ __forceinline__ void glds16_batch_w(const void* sbase, unsigned voff, unsigned lds_piece4) {
+    static_assert(N == 3 || N == 5, "batch sizes in use");
+    const unsigned long long b = (unsigned long long)sbase;
+    const unsigned long long sb = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) << 32) |
+                                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)b);
+    lds_piece4 = __builtin_amdgcn_readfirstlane(lds_piece4);
+    if constexpr (N == 5)
+        asm volatile(
+            "s_nop 4\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %0, %1 offset:-4096\n\t"
+            "global_load_lds_dwordx4 %0, %1 offset:-3072\n\t"
+            "global_load_lds_dwordx4 %0, %1 offset:-2048\n\t"
+            "global_load_lds_dwordx4 %0, %1 offset:-1024\n\t"
+            "global_load_lds_dwordx4 %0, %1"
+            :
+            : "v"(voff), "s"(sb), "s"(lds_piece4)
+            : "memory");
+    else
+        asm volatile(
+            "s_nop 4\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %0, %1 offset:-4096\n\t"
+            "global_load_lds_dwordx4 %0, %1 offset:-3072\n\t"
+            "global_load_lds_dwordx4 %0, %1 offset:-2048"
+            :
+            : "v"(voff), "s"(sb), "s"(lds_piece4)
+            : "memory");
+}
+// Five pieces with their own per-lane offsets (activations); voff[i] already contains -(i - 4) KiB.
+__device__ __forceinline__ void glds16_batch_a(const void* sbase, const unsigned (&voff)[5], unsigned lds_piece4) {
+    const unsigned long long b = (unsigned long long)sbase;
+    const unsigned long long sb = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) << 32) |
+                                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)b);
+    lds_piece4 = __builtin_amdgcn_readfirstlane(lds_piece4);
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 m0, %6\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %5 offset:-4096\n\t"
+        "global_load_lds_dwordx4 %1, %5 offset:-3072\n\t"
+        "global_load_lds_dwordx4 %2, %5 offset:-2048\n\t"
+        "global_load_lds_dwordx4 %3, %5 offset:-1024\n\t"
+        "global_load_lds_dwordx4 %4, %5"
+        :
+        : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]), "s"(sb), "s"(lds_piece4)
+        : "memory");
+}
+
+// The same transfer with a per-lane 64-bit source address (border tiles: pieces outside the image read the zero page, so
+// every wave still issues exactly one DMA per piece - the counted vmcnt waits rely on that).
+__device__ __forceinline__ void glds16_v(const void* gsrc, unsigned lds_dst) {
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
     asm volatile(
         "s_mov_b32 m0, %1\n\t"
         "s_nop 0\n\t"
@@ -151,9 +232,9 @@ unsigned long long* stamp_buffer(int which);
 // before its first use.
 // dma_slot(k), k = 0..35, is called after every 2*(NW - W_LO) MFMAs; on_centre(xc) once with the centre-tap B fragments
 // xc[row][ph] (the wave's own pixels).
-template <typename T, int NW, int W_LO, typename WIdx, typename Slot, typename Centre>
+template <typename T, int NW, int W_LO, typename WIdx, typename Slot, typename Centre, typename Hook>
 __device__ __forceinline__ void conv_item(f32x4 (&acc)[RPW][NW][2], const uint4* a, const uint4* wl, const int (&rd_off)[3][2],
-                                          WIdx widx, Slot dma_slot, Centre on_centre) {
+                                          WIdx widx, Slot dma_slot, Centre on_centre, Hook step_hook) {
     constexpr int NWU = NW - W_LO;
     constexpr int NK = 9 * NWU;  // weight fragments of the item, in use order
     uint4 xr[RPW + 2][2];
@@ -204,6 +285,7 @@ __device__ __forceinline__ void conv_item(f32x4 (&acc)[RPW][NW][2], const uint4*
             on_centre(xc);
             FW_SB();
         }
+        step_hook(t);  // diagnostics only (phase stamps)
     }
 }
 
