@@ -28,7 +28,7 @@
 namespace fw {
 
 template <typename T, int CT, int EPI>
-__global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kernel(const ConvParams p) {
     using SM = Smem<CT>;
     __shared__ __attribute__((aligned(16))) uint4 lds[SM::TOTAL];
     constexpr int NA = SM::NA;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
         // nearest-x2 input reads source pixel (y >> 1, x >> 1); ((row - 1) >> 1) + 1 >= 0 for row >= 0
         const int srow = ups ? (((row - 1) >> 1) + 1) : row;
         const int spx = ups ? (((px - 1) >> 1) + 1) : px;
-        relb[i] = (unsigned)(((srow * Ws + spx) * p.in_cstride + s * 8) * 2) + (unsigned)(4 - i) * 1024u;
+        relb[i] = (unsigned)(((srow * Ws + spx) * p.in_cstride + s * 8) * 2) + (unsigned)(4 - i % 5) * 1024u;
     }
     const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)lds;
     const char* in = reinterpret_cast<const char*>(p.in);
@@ -119,11 +119,12 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
         if (a_c == 0) plan_tile();
         const unsigned dst = (unsigned)((a_n % NA) * ACT_REGION + ACT_ITERS * wave * 64);  // the wave's first piece
         if (a_all) {
-            glds16_batch_a(a_src, relb, lds_base + (dst + 4 * 64) * 16u);
+#pragma unroll
+            for (int bt = 0; bt < ACT_ITERS / 5; ++bt) glds16_batch_a(a_src, relb + 5 * bt, lds_base + (dst + (5 * bt + 4) * 64) * 16u);
         } else {
 #pragma unroll
             for (int i = 0; i < ACT_ITERS; ++i)
-                glds16_v(((a_ok >> i) & 1u) ? a_src + (relb[i] - (unsigned)(4 - i) * 1024u) : reinterpret_cast<const char*>(p.zeros),
+                glds16_v(((a_ok >> i) & 1u) ? a_src + (relb[i] - (unsigned)(4 - i % 5) * 1024u) : reinterpret_cast<const char*>(p.zeros),
                          lds_base + (dst + i * 64) * 16u);
         }
         ++a_n;
@@ -138,16 +139,10 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
     // (5, 5, 5, 3), waves 0-3 the first half, waves 4-7 the second (CT == 2).  They are OLDER than the activation pieces
     // issued after them, which is what the counted vmcnt of the 3-stage pipeline relies on.
     auto issue_w = [&](int c, int ws) {
-        const int half = wave >> 2, k = wave & 3;
-        if (half < CT) {
-            const int f4 = W_FRAGS * half + 5 * k + 4;  // the batch's fifth fragment
-            const char* src = w_b + (size_t)c * (W_FRAGS * CT * 1024) + f4 * 1024;
-            const unsigned dst = lds_base + (unsigned)(SM::W_BASE + ws * SM::W_REGION + f4 * 64) * 16u;
-            if (k < 3)
-                glds16_batch_w<5>(src, lane16, dst);
-            else
-                glds16_batch_w<3>(src, lane16, dst);
-        }
+        const int half = wave / (NWAVES / 2), k = wave % (NWAVES / 2);
+        if (half < CT)
+            issue_w_half(w_b + (size_t)c * (W_FRAGS * CT * 1024) + W_FRAGS * half * 1024,
+                         lds_base + (unsigned)(SM::W_BASE + ws * SM::W_REGION + W_FRAGS * half * 64) * 16u, k, lane16);
     };
 
     // ---- fragment-read plan ------------------------------------------------------------------------------------
@@ -227,7 +222,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
             // item n has landed (each wave waits for its own DMAs, then the barrier) and every wave is done reading
             // the stages that are refilled during this item
             if (NA == 3 && n + 1 < nitems)
-                FW_WAIT_VMCNT(5);  // ACT_ITERS: activations(n+1) may stay in flight
+                FW_WAIT_VMCNT(ACT_ITERS);  //: activations(n+1) may stay in flight
             else
                 FW_WAIT_VMCNT(0);
             FW_STAMP(5);  // this wave's own DMAs
@@ -239,8 +234,8 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
             // The two DMA batches of this boundary (weights of item n+1, activations of item n+NA-1) go out in the shadow
             // of the first MFMAs: slot d of 36, compile-time after unrolling.
 #ifndef FW_DMA_SLOT_W
-#define FW_DMA_SLOT_W 0
-#define FW_DMA_SLOT_A 2
+#define FW_DMA_SLOT_W 2
+#define FW_DMA_SLOT_A 6
 #endif
             auto dma_slot = [&](int d) {
                 if (d == FW_DMA_SLOT_W) {
@@ -281,7 +276,15 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_mfma_kernel(const Conv
                         if (c < CT && p.in_id_scale != 0.f) add_identity(xc, p.in_id_scale, c);
                     }
                 },
-                [](int) {});
+                [&](int step) {
+#ifdef FW_PRIO_ALT
+                    if (wave >= NWAVES / 2) {
+                        if (step & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+                    } else {
+                        if (step & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
+                    }
+#endif
+                });
             FW_STAMP(1);  // item compute
             if constexpr (SPLIT) {
                 if (has_id) add_identity(idx, p.id_scale[c], c & 1);
@@ -439,7 +442,7 @@ extern "C" int fw_debug_stamps(int which, unsigned long long* out) {
 }
 #endif
 
-static_assert(ACT_ITERS == 5, "the counted s_waitcnt vmcnt(5) and the 5-piece DMA batch assume 5 activation pieces per wave");
+static_assert(ACT_ITERS % 5 == 0, "activation pieces go out in batches of five");
 
 // 256 bytes of zeros per device: the DMA source of halo positions outside the image.
 static const void* zero_page() {

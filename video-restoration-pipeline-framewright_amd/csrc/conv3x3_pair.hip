@@ -36,7 +36,7 @@ struct PairSmem {
 };
 
 template <typename T>
-__global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const ConvPairParams p) {
+__global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_kernel(const ConvPairParams p) {
     using SM = PairSmem;
     __shared__ __attribute__((aligned(16))) uint4 lds[SM::TOTAL];
     constexpr int NW = 4;  // accumulator tiles of 16 output channels: 0,1 = conv_a, 2,3 = conv_b
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
         const int rm = idx - row * ROW_PIECES;
         const int px = rm >> 2;
         const int s = (rm & 3) ^ halo_swz(px);
-        relb[i] = (unsigned)(((row * p.W + px) * p.in_cstride + s * 8) * 2) + (unsigned)(4 - i) * 1024u;
+        relb[i] = (unsigned)(((row * p.W + px) * p.in_cstride + s * 8) * 2) + (unsigned)(4 - i % 5) * 1024u;
     }
     const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)lds;
     const char* in = reinterpret_cast<const char*>(p.in);
@@ -119,11 +119,12 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
         if (f_c == 0) plan_tile();
         const unsigned dst = (unsigned)(stage * ACT_REGION + ACT_ITERS * wave * 64);  // the wave's first piece
         if (f_all) {
-            glds16_batch_a(f_src, relb, lds_base + (dst + 4 * 64) * 16u);
+#pragma unroll
+            for (int bt = 0; bt < ACT_ITERS / 5; ++bt) glds16_batch_a(f_src, relb + 5 * bt, lds_base + (dst + (5 * bt + 4) * 64) * 16u);
         } else {
 #pragma unroll
             for (int i = 0; i < ACT_ITERS; ++i)
-                glds16_v(((f_ok >> i) & 1u) ? f_src + (relb[i] - (unsigned)(4 - i) * 1024u) : reinterpret_cast<const char*>(p.zeros),
+                glds16_v(((f_ok >> i) & 1u) ? f_src + (relb[i] - (unsigned)(4 - i % 5) * 1024u) : reinterpret_cast<const char*>(p.zeros),
                          lds_base + (dst + i * 64) * 16u);
         }
         if (++f_c == na) {
@@ -136,16 +137,10 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
     // weights of item j of a tile -> weight stage ws: fragments [0,18) = conv_a chunk j (waves 0-3: 5, 5, 5, 3 fragments),
     // [18,36) = conv_b chunk j (waves 4-7); the last item (j == na) only has conv_b's chunk
     auto issue_w = [&](int j, int ws) {
-        const int half = wave >> 2, k = wave & 3;
-        if (half == 1 || j < na) {
-            const int f4 = 5 * k + 4;  // the batch's fifth fragment within its half
-            const char* src = (half ? wb_b : wa_b) + (size_t)j * (W_FRAGS * 1024) + f4 * 1024;
-            const unsigned dst = lds_base + (unsigned)(SM::W_BASE + ws * SM::W_REGION + (W_FRAGS * half + f4) * 64) * 16u;
-            if (k < 3)
-                glds16_batch_w<5>(src, lane16, dst);
-            else
-                glds16_batch_w<3>(src, lane16, dst);
-        }
+        const int half = wave / (NWAVES / 2), k = wave % (NWAVES / 2);
+        if (half == 1 || j < na)
+            issue_w_half((half ? wb_b : wa_b) + (size_t)j * (W_FRAGS * 1024),
+                         lds_base + (unsigned)(SM::W_BASE + ws * SM::W_REGION + W_FRAGS * half * 64) * 16u, k, lane16);
     };
 
     int rd_off[3][2];  // [dx][ph]: piece index of (halo row RPW*wave, px 16*ph + q + dx, slot sl)
@@ -242,8 +237,8 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
             const bool fetch = !(FW_PAIR_DBG & 1) && BOTH && more && (j + 1 < na || t + 1 < t_hi);
             const int fetch_stage = (qd + 1) & 1;
 #ifndef FW_DMA_SLOT_W
-#define FW_DMA_SLOT_W 0
-#define FW_DMA_SLOT_A 2
+#define FW_DMA_SLOT_W 2
+#define FW_DMA_SLOT_A 6
 #endif
             auto dma_slot = [&](int d) {
                 if (d == FW_DMA_SLOT_W) {
@@ -257,6 +252,13 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_pair_kernel(const Conv
             const uint4* wl = lds + SM::W_BASE + (n & 1) * SM::W_REGION + lane;
             auto& slot_fn = dma_slot;
             conv_item<T, NW, BOTH ? 0 : 2>(acc, a, wl, rd_off, widx, slot_fn, [](const uint4 (&)[RPW][2]) {}, [&](int step) {
+#ifdef FW_PRIO_ALT  // experiment: the two waves of a SIMD take turns at priority 1, one step each
+                if (wave >= NWAVES / 2) {
+                    if (step & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+                } else {
+                    if (step & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
+                }
+#endif
 #ifdef FW_STEP_STAMPS  // BOTH items: slot 1 = steps 0-2 (the DMA slots), 6 = steps 3-5, 4 = steps 6-8
                 if (BOTH && step == 2) FW_STAMP(1);
                 if (BOTH && step == 5) FW_STAMP(6);

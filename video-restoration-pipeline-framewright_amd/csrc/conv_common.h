@@ -52,7 +52,13 @@ constexpr int ROW_PIECES = HALO_W * 4;                    // 136 16-byte pieces 
 constexpr int ACT_PIECES = HALO_H * ROW_PIECES;           // 2448 pieces per 32-channel chunk
 constexpr int ACT_INSTR = 40;                            // wave-instructions of 1 KiB per chunk (39 used + 1 pad)
 constexpr int ACT_REGION = ACT_INSTR * 64;                // 2560 pieces = 40 KiB per stage
-constexpr int NWAVES = 8;                                 // 512 threads: two waves per SIMD hide each other's stalls
+#ifndef FW_NWAVES
+#define FW_NWAVES 8
+#endif
+constexpr int NWAVES = FW_NWAVES;                         // 8: two waves per SIMD hide each other's stalls; 4: one per SIMD,
+                                                          // four rows per wave, 40 % fewer LDS read bytes per MFMA
+static_assert(NWAVES == 4 || NWAVES == 8, "waves per workgroup");
+constexpr int WAVES_PER_SIMD = NWAVES / 4;
 constexpr int RPW = TILE_H / NWAVES;                      // output rows per wave (2)
 constexpr int ACT_ITERS = ACT_INSTR / NWAVES;             // 5 per wave, every wave issues all of them
 constexpr int W_FRAGS = 18;                               // 9 taps x 2 k-steps of 16, per cout tile
@@ -114,7 +120,7 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
 // Same per-lane offset for every piece (weights: the source is as linear as the LDS image).
 template <int N>
 __device__ __forceinline__ void glds16_batch_w(const void* sbase, unsigned voff, unsigned lds_piece4) {
-    static_assert(N == 3 || N == 5, "batch sizes in use");
+    static_assert(N >= 3 && N <= 5, "batch sizes in use");
     const unsigned long long b = (unsigned long long)sbase;
     const unsigned long long sb = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) << 32) |
                                   (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)b);
@@ -132,6 +138,18 @@ __device__ __forceinline__ void glds16_batch_w(const void* sbase, unsigned voff,
             :
             : "v"(voff), "s"(sb), "s"(lds_piece4)
             : "memory");
+    else if constexpr (N == 4)
+        asm volatile(
+            "s_nop 4\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %0, %1 offset:-4096\n\t"
+            "global_load_lds_dwordx4 %0, %1 offset:-3072\n\t"
+            "global_load_lds_dwordx4 %0, %1 offset:-2048\n\t"
+            "global_load_lds_dwordx4 %0, %1 offset:-1024"
+            :
+            : "v"(voff), "s"(sb), "s"(lds_piece4)
+            : "memory");
     else
         asm volatile(
             "s_nop 4\n\t"
@@ -145,7 +163,7 @@ __device__ __forceinline__ void glds16_batch_w(const void* sbase, unsigned voff,
             : "memory");
 }
 // Five pieces with their own per-lane offsets (activations); voff[i] already contains -(i - 4) KiB.
-__device__ __forceinline__ void glds16_batch_a(const void* sbase, const unsigned (&voff)[5], unsigned lds_piece4) {
+__device__ __forceinline__ void glds16_batch_a(const void* sbase, const unsigned* voff, unsigned lds_piece4) {
     const unsigned long long b = (unsigned long long)sbase;
     const unsigned long long sb = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) << 32) |
                                   (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)b);
@@ -175,6 +193,23 @@ __device__ __forceinline__ void glds16_v(const void* gsrc, unsigned lds_dst) {
         :
         : "v"(gsrc), "s"(lds_dst)
         : "memory");
+}
+
+// The 18 weight fragments of one 32-output-channel half, split over the NWAVES/2 waves that own the half: 8 waves -> 5, 5,
+// 5, 3 fragments; 4 waves -> 9 each, as batches of 5 + 4.  `src`/`dst` address fragment 0 of the half (global / LDS byte
+// address), k = the wave's index within the half.
+__device__ __forceinline__ void issue_w_half(const char* src, unsigned dst, int k, unsigned lane16) {
+    if constexpr (NWAVES == 8) {
+        const int f4 = 5 * k + 4;  // the batch's fifth fragment
+        if (k < 3)
+            glds16_batch_w<5>(src + f4 * 1024, lane16, dst + f4 * 1024);
+        else
+            glds16_batch_w<3>(src + f4 * 1024, lane16, dst + f4 * 1024);
+    } else {
+        const int f4 = 9 * k + 4;
+        glds16_batch_w<5>(src + f4 * 1024, lane16, dst + f4 * 1024);
+        glds16_batch_w<4>(src + (f4 + 5) * 1024, lane16, dst + (f4 + 5) * 1024);
+    }
 }
 
 // Phase stamps (diagnostic build -DFW_PAIR_STAMP only; in the product build no stamp executes): every wave accumulates
@@ -281,7 +316,11 @@ __device__ __forceinline__ void conv_item(f32x4 (&acc)[RPW][NW][2], const uint4*
             FW_SB();
         }
         if (dx == 1 && dy == 1) {
-            const uint4 xc[RPW][2] = {{xr[1][0], xr[1][1]}, {xr[2][0], xr[2][1]}};
+            uint4 xc[RPW][2];
+#pragma unroll
+            for (int row = 0; row < RPW; ++row)
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) xc[row][ph] = xr[row + 1][ph];
             on_centre(xc);
             FW_SB();
         }
