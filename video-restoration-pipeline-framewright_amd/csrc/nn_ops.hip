@@ -397,7 +397,18 @@ __global__ __launch_bounds__(256) void dwconv3x3_gate_kernel(const T* __restrict
     // wdw: [2C][9] fp32, bdw: [2C].  groups = C/8 divides 256 (C is a power-of-two multiple of 32 here), so a thread keeps
     // the same channel group for its whole grid-stride loop and the SCA pooling is a fixed-order (deterministic) reduction:
     // registers -> LDS -> partial[block][C] -> sca_kernel.
-    __shared__ float red[256][8];
+    // The filters sit in LDS transposed to [tap][2C] (dynamic shared memory, 72*C bytes): a thread reads its 8 + 8 weights of
+    // a tap as four ds_read_b128, and the products take the typed input straight into an fp32 FMA (v_fma_mix_f32 for
+    // f16) - 36 LDS reads + 144 FMAs per 8 output channels where the first version issued 144 global loads + 144
+    // conversions + 144 FMAs.
+    extern __shared__ __attribute__((aligned(16))) float dw_smem[];
+    float* wl = dw_smem;                                     // [9][2C]
+    float (*red)[8] = reinterpret_cast<float (*)[8]>(dw_smem + 18 * C);  // [256][8]
+    for (int i = threadIdx.x; i < 18 * C; i += 256) {
+        const int ch = i / 9, tap = i - ch * 9;
+        wl[tap * 2 * C + ch] = wdw[i];
+    }
+    __syncthreads();
     const int groups = C / 8;
     const long total = (long)H * W * groups;
     const int g = threadIdx.x % groups;
@@ -408,8 +419,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_gate_kernel(const T* __restrict
         br[0][j] = bdw[g * 8 + j];
         br[1][j] = bdw[C + g * 8 + j];
     }
-    const float* w1p = wdw + (size_t)(g * 8) * 9;        // this thread's 8 + 8 filters (L1 resident: 72 floats each)
-    const float* w2p = wdw + (size_t)(C + g * 8) * 9;
+    const float* w1p = wl + g * 8;
+    const float* w2p = wl + C + g * 8;
+    using V8 = typename Tr<T>::v8;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const long pix = idx / groups;
         const int yy = (int)(pix / W), xx = (int)(pix - (long)yy * W);
@@ -428,14 +440,19 @@ __global__ __launch_bounds__(256) void dwconv3x3_gate_kernel(const T* __restrict
                 const int sx = xx + dx;
                 if (sx < 0 || sx >= W) continue;
                 const T* src = x + ((long)sy * W + sx) * (2 * C);
-                float f1[8], f2[8];
-                unpack8f<T>(*reinterpret_cast<const uint4*>(src + g * 8), f1);
-                unpack8f<T>(*reinterpret_cast<const uint4*>(src + C + g * 8), f2);
+                const V8 f1 = __builtin_bit_cast(V8, *reinterpret_cast<const uint4*>(src + g * 8));
+                const V8 f2 = __builtin_bit_cast(V8, *reinterpret_cast<const uint4*>(src + C + g * 8));
                 const int tap = (dy + 1) * 3 + (dx + 1);
+                const f32x4 wa0 = *reinterpret_cast<const f32x4*>(w1p + tap * 2 * C);
+                const f32x4 wa1 = *reinterpret_cast<const f32x4*>(w1p + tap * 2 * C + 4);
+                const f32x4 wb0 = *reinterpret_cast<const f32x4*>(w2p + tap * 2 * C);
+                const f32x4 wb1 = *reinterpret_cast<const f32x4*>(w2p + tap * 2 * C + 4);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    a1[j] += f1[j] * w1p[j * 9 + tap];
-                    a2[j] += f2[j] * w2p[j * 9 + tap];
+                for (int j = 0; j < 4; ++j) {
+                    a1[j] += (float)f1[j] * wa0[j];
+                    a1[4 + j] += (float)f1[4 + j] * wa1[j];
+                    a2[j] += (float)f2[j] * wb0[j];
+                    a2[4 + j] += (float)f2[4 + j] * wb1[j];
                 }
             }
         }
@@ -478,24 +495,45 @@ void launch_dwconv3x3_gate(DType dt, const void* x, int H, int W, int C, const f
                            float* partial, hipStream_t st) {
     if (C < 32 || (C & (C - 1)) || C > 1024) throw Error(1, "dwconv3x3_gate: C must be a power of two in [32, 1024]");
     const int blocks = dwconv_blocks(H, W, C);
+    const size_t smem = ((size_t)18 * C + 256 * 8) * sizeof(float);  // filters [9][2C] + pooling scratch (<= 80 KiB)
+    static const bool attr_set = [] {
+        const int cap = (18 * 1024 + 256 * 8) * (int)sizeof(float);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_gate_kernel<__bf16>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_gate_kernel<_Float16>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        return true;
+    }();
+    (void)attr_set;
     if (dt == DT_BF16)
-        hipLaunchKernelGGL((dwconv3x3_gate_kernel<__bf16>), dim3((unsigned)blocks), dim3(256), 0, st, (const __bf16*)x, H,
+        hipLaunchKernelGGL((dwconv3x3_gate_kernel<__bf16>), dim3((unsigned)blocks), dim3(256), smem, st, (const __bf16*)x, H,
                            W, C, wdw, bdw, (__bf16*)out, partial);
     else
-        hipLaunchKernelGGL((dwconv3x3_gate_kernel<_Float16>), dim3((unsigned)blocks), dim3(256), 0, st,
+        hipLaunchKernelGGL((dwconv3x3_gate_kernel<_Float16>), dim3((unsigned)blocks), dim3(256), smem, st,
                            (const _Float16*)x, H, W, C, wdw, bdw, (_Float16*)out, partial);
     FW_HIP_CHECK(hipGetLastError());
 }
 
 // SCA: mean[k] = (sum over blocks of partial[b][k]) / HW, summed in block order (deterministic); then
 // s[n] = b[n] + sum_k W[n][k] * mean[k], one wave per output channel.
-__global__ __launch_bounds__(256) void sca_mean_kernel(const float* __restrict__ partial, int nblocks, float inv_hw, int C,
-                                                       float* mean) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= C) return;
+__global__ __launch_bounds__(1024) void sca_mean_kernel(const float* __restrict__ partial, int nblocks, float inv_hw, int C,
+                                                        float* mean) {
+    // workgroup = 64 channels x 16 slices of the block list; slice s sums blocks s, s+16, ... in order, then one thread per
+    // channel adds the 16 slice sums in order: a fixed summation tree, deterministic
+    __shared__ float part[16][64];
+    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + c;
     float m = 0.f;
-    for (int q = 0; q < nblocks; ++q) m += partial[(long)q * C + k];
-    mean[k] = m * inv_hw;
+    if (k < C)
+        for (int q = sl; q < nblocks; q += 16) m += partial[(long)q * C + k];
+    part[sl][c] = m;
+    __syncthreads();
+    if (sl == 0 && k < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += part[i][c];
+        mean[k] = t * inv_hw;
+    }
 }
 
 __global__ __launch_bounds__(256) void sca_kernel(const float* __restrict__ mean, int C, const float* w, const float* b,
@@ -514,7 +552,7 @@ __global__ __launch_bounds__(256) void sca_kernel(const float* __restrict__ mean
 void launch_sca(const float* partial, int nblocks, long HW, int C, const float* w, const float* b, float* s,
                 hipStream_t st) {
     float* mean = s + C;
-    hipLaunchKernelGGL(sca_mean_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, nblocks, 1.0f / (float)HW, C, mean);
+    hipLaunchKernelGGL(sca_mean_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, partial, nblocks, 1.0f / (float)HW, C, mean);
     hipLaunchKernelGGL(sca_kernel, dim3((C * 64 + 255) / 256), dim3(256), 0, st, (const float*)mean, C, w, b, s);
     FW_HIP_CHECK(hipGetLastError());
 }
