@@ -141,6 +141,21 @@ int fw_conv3x3_nhwc_ex(int dtype, const void* x, int in_cstride, long in_plane_s
                        int post_act, int f32_cstride, int f32_coff, void* out, int out_cstride, long out_plane_stride,
                        int out_coff, float* out_f32, void* stream);
 
+/* act_lrelu == 2 in fw_conv3x3_nhwc_ex (res1 == NULL): PReLU, y = max(t, 0) + chan_scale[n] * min(t, 0) with t = acc + bias —
+ * the activation of SRVGGNetCompact (realesr-animevideov3, realesr-general-x4v3). */
+
+/* uint8 BGR H x W x 3 -> operand-typed [H][W][out_cstride] RGB/255 in channels 0..2, zeros above (out_cstride >= 32).
+ * replaces  img.astype(float32)/255 + BGR->RGB + HWC->CHW of RealESRGANer.pre_process (third-party; call site
+ *           processors/pytorch_realesrgan.py:223). */
+int fw_u8_to_nhwc(int dtype, const uint8_t* in_bgr, int height, int width, void* out, int out_cstride, void* stream);
+
+/* SRVGGNetCompact tail: out = PixelShuffle(scale)(conv) + nearest-upsample(input), conv = fp32 [H][W][conv_cstride] with
+ * channel c*scale^2 + i*scale + j; RGB float [scale*H][scale*W][3] and/or clamp -> x255 -> rint -> uint8 BGR.
+ * replaces  the tail of the SRVGGNetCompact forward (third-party `realesrgan.archs.srvgg_arch`; the reference declares
+ *           these checkpoints at processors/pytorch_realesrgan.py:119-128). */
+int fw_pixel_shuffle_add_u8(const float* conv, int conv_cstride, const uint8_t* in_bgr, int height, int width, int scale,
+                            uint8_t* out_bgr, float* out_rgb_f32, void* stream);
+
 /* Two chained growth convolutions of a residual dense block in one kernel (aesrgan_face.py:184-187):
  *   x_a = lrelu(conv_a(x[0 : 32*in_chunks]) + bias_a)            (32 channels) -> out_a
  *   x_b = lrelu(conv_b(cat(x[0 : 32*in_chunks], x_a)) + bias_b)  (32 channels) -> out_b

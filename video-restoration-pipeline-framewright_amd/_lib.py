@@ -30,6 +30,7 @@ EXPORTS = [
     "fw_strength_blend_u8",
     "fw_conv3x3_nhwc_ex", "fw_conv3x3_pair_nhwc", "fw_u8_to_rgb_f32", "fw_resize_bilinear_f32", "fw_ifnet_build_x", "fw_unshuffle2_cast",
     "fw_depth_to_space4_f32", "fw_ifnet_accumulate", "fw_ifnet_blend",
+    "fw_u8_to_nhwc", "fw_pixel_shuffle_add_u8",
 ]
 
 
@@ -129,6 +130,10 @@ def _declare_ifnet(lib: C.CDLL) -> None:
     lib.fw_ifnet_accumulate.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp, i32, vp]
     lib.fw_ifnet_blend.restype = i32
     lib.fw_ifnet_blend.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
+    lib.fw_u8_to_nhwc.restype = i32
+    lib.fw_u8_to_nhwc.argtypes = [i32, vp, i32, i32, vp, i32, vp]
+    lib.fw_pixel_shuffle_add_u8.restype = i32
+    lib.fw_pixel_shuffle_add_u8.argtypes = [vp, i32, vp, i32, i32, i32, vp, vp, vp]
 
 
 def load() -> C.CDLL:

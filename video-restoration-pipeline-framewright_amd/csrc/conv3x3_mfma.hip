@@ -358,9 +358,13 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
                                     }
                                 }
                             } else {
-                                if (p.act) {
+                                if (p.act == 1) {
 #pragma unroll
                                     for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.2f * o[j]);
+                                } else if (p.act == 2) {  // PReLU, per-channel slopes in chan_scale (SRVGGNetCompact)
+                                    const f32x4 sl4 = *reinterpret_cast<const f32x4*>(p.chan_scale + 16 * w + 4 * sl);
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) o[j] = o[j] > 0.f ? o[j] : sl4[j] * o[j];
                                 }
                             }
                             if (p.out_f32 && fok) *reinterpret_cast<f32x4*>(p.out_f32 + fo) = o;
@@ -516,6 +520,7 @@ void launch_conv3x3(DType dt, int cout_tiles, ConvEpilogue epi, const ConvParams
     if (p.out && cout_tiles == 2 && (p.out_pstride < 32 || (p.out_pstride & 7)))
         throw Error(1, "conv3x3: bad output plane stride");
     if (p.out && ((p.out_cstride & 7) || (p.out_coff & 7))) throw Error(1, "conv3x3: output slice must be 16-byte aligned");
+    if (p.act == 2 && !p.chan_scale) throw Error(1, "conv3x3: PReLU needs its slopes");
     if (p.out_lo && (cout_tiles != 2 || !p.out || epi == EPI_IMAGE)) throw Error(1, "conv3x3: out_lo needs a 64-channel typed output");
     if (epi == EPI_RESIDUAL_SPLIT) {
         if (cout_tiles != 2 || p.upsample2x || !p.out || !p.out_lo || p.n_id < 0 || p.n_id > 6 || p.n_id > p.cin_chunks)

@@ -94,6 +94,43 @@ void launch_u8_to_nhwc(DType dt, const uint8_t* in_bgr, int H, int W, void* out,
 }
 
 
+// ---- SRVGGNetCompact tail (Real-ESRGAN realesr-animevideov3 / realesr-general-x4v3; reference model table
+//      src/framewright/processors/pytorch_realesrgan.py:119-128 declares them, the network itself is third-party) ---------
+__global__ __launch_bounds__(256) void pixel_shuffle_add_kernel(const float* __restrict__ conv, int cstride,
+                                                                const uint8_t* __restrict__ in_bgr, int H, int W, int s,
+                                                                uint8_t* out_bgr, float* out_rgb) {
+    const int Wo = W * s;
+    const long n = (long)H * s * Wo;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int Y = (int)(i / Wo), X = (int)(i - (long)Y * Wo);
+        const int y = Y / s, x = X / s, sub = (Y - y * s) * s + (X - x * s);
+        const float* c = conv + ((size_t)y * W + x) * cstride;
+        const uint8_t* px = in_bgr + ((size_t)y * W + x) * 3;
+        float v[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) v[ch] = c[ch * s * s + sub] + px[2 - ch] / 255.0f;
+        if (out_rgb) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) out_rgb[(size_t)i * 3 + ch] = v[ch];
+        }
+        if (out_bgr) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)
+                out_bgr[(size_t)i * 3 + 2 - ch] = (uint8_t)rintf(fminf(fmaxf(v[ch], 0.f), 1.f) * 255.f);
+        }
+    }
+}
+
+void launch_pixel_shuffle_add(const float* conv, int cstride, const uint8_t* in_bgr, int H, int W, int scale, uint8_t* out_bgr,
+                              float* out_rgb, hipStream_t st) {
+    if (scale < 1 || scale > 4 || cstride < 3 * scale * scale) throw Error(1, "pixel_shuffle_add: bad scale / channel stride");
+    const long n = (long)H * scale * W * scale;
+    const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(pixel_shuffle_add_kernel, dim3(blocks), dim3(256), 0, st, conv, cstride, in_bgr, H, W, scale, out_bgr,
+                       out_rgb);
+    FW_HIP_CHECK(hipGetLastError());
+}
+
 // ---- TAP (NAFNet) frame path ---------------------------------------------------------------------------------
 // uint8 BGR H x W x 3 -> typed [Hp][Wp][32] RGB/255 with zeros outside H x W (NAFNet.check_image_size zero pad,
 // SURVEY.md §A.3; pre-processing reference src/framewright/processors/tap_denoise.py:373-397).

@@ -50,7 +50,7 @@ struct ConvParams {
     uint8_t* out_u8;       // EPI_IMAGE: HxWx3 BGR uint8 (optional)
     float* out_rgb;        // EPI_IMAGE: HxWx3 RGB float, un-clamped (optional)
     int img_H, img_W;      // EPI_IMAGE: size of the stored image (crop of the H x W conv output; mod-pad removal)
-    int act;               // 1 = LeakyReLU(0.2) (EPI_STORE only)
+    int act;               // EPI_STORE: 1 = LeakyReLU(0.2), 2 = PReLU with per-output-channel slopes in chan_scale
     int upsample2x;        // 1 = input is nearest-neighbour x2 upsampled on the fly
     const float* chan_scale;  // EPI_RESIDUAL: optional per-output-channel factor, y = (acc+bias)*chan_scale[n]*s1 + res1
     int post_act;          // EPI_RESIDUAL: 1 = LeakyReLU(0.2) after the residual add (IFNet ResConv)
@@ -106,6 +106,10 @@ size_t pack_conv3x3_weights(DType dt, const float* w, int cout, int cin, int cou
 // 2 = pixel_unshuffle(2) front end of the x2 model (12 channels), with reflect mod-padding to even size.
 void launch_u8_to_nhwc(DType dt, const uint8_t* in_bgr, int H, int W, void* out, int out_cstride,
                        int unshuffle, hipStream_t stream);
+// SRVGGNetCompact tail: PixelShuffle(scale) of the last conv (fp32 [H][W][cstride], channel c*scale^2 + i*scale + j) plus
+// the nearest-upsampled input, -> RGB float and/or clamp -> x255 -> rint -> uint8 BGR, both [scale*H][scale*W][3].
+void launch_pixel_shuffle_add(const float* conv, int cstride, const uint8_t* in_bgr, int H, int W, int scale, uint8_t* out_bgr,
+                              float* out_rgb, hipStream_t stream);
 
 // ---- NAFNet building blocks (nn_ops.hip) -------------------------------------------------------------
 enum PointwiseMode : int {

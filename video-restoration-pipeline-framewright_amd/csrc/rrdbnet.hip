@@ -642,6 +642,7 @@ int fw_conv3x3_nhwc_ex(int dtype, const void* x, int in_cstride, long in_plane_s
     if (cout_tiles != 1 && cout_tiles != 2) return fail(FW_ERR_INVALID, "fw_conv3x3_nhwc: cout_tiles must be 1 or 2");
     if (res1 && cout_tiles != 2) return fail(FW_ERR_INVALID, "fw_conv3x3_nhwc: residual epilogue needs 64 channels");
     if (!res1 && res2) return fail(FW_ERR_INVALID, "fw_conv3x3_nhwc: res2 without res1");
+    if (act_lrelu == 2 && (res1 || !chan_scale)) return fail(FW_ERR_INVALID, "fw_conv3x3_nhwc: PReLU needs slopes and no residual");
     return guarded([&] {
         ConvParams p{};
         p.in = x;
@@ -668,6 +669,21 @@ int fw_conv3x3_nhwc_ex(int dtype, const void* x, int in_cstride, long in_plane_s
         p.f32_cstride = f32_cstride;
         p.f32_coff = f32_coff;
         launch_conv3x3((DType)dtype, cout_tiles, res1 ? EPI_RESIDUAL : EPI_STORE, p, (hipStream_t)stream);
+    });
+}
+
+int fw_u8_to_nhwc(int dtype, const uint8_t* in_bgr, int H, int W, void* out, int out_cstride, void* stream) {
+    if (!in_bgr || !out || H < 1 || W < 1) return fail(FW_ERR_INVALID, "fw_u8_to_nhwc: bad argument");
+    if (dtype != FW_DTYPE_BF16 && dtype != FW_DTYPE_F16) return fail(FW_ERR_INVALID, "fw_u8_to_nhwc: bad dtype");
+    return guarded([&] { launch_u8_to_nhwc((DType)dtype, in_bgr, H, W, out, out_cstride, 1, (hipStream_t)stream); });
+}
+
+int fw_pixel_shuffle_add_u8(const float* conv, int conv_cstride, const uint8_t* in_bgr, int H, int W, int scale,
+                            uint8_t* out_bgr, float* out_rgb_f32, void* stream) {
+    if (!conv || !in_bgr || (!out_bgr && !out_rgb_f32) || H < 1 || W < 1)
+        return fail(FW_ERR_INVALID, "fw_pixel_shuffle_add_u8: bad argument");
+    return guarded([&] {
+        launch_pixel_shuffle_add(conv, conv_cstride, in_bgr, H, W, scale, out_bgr, out_rgb_f32, (hipStream_t)stream);
     });
 }
 

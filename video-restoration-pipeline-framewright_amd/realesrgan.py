@@ -289,8 +289,16 @@ def get_upsampler(config: PyTorchESRGANConfig) -> HipRealESRGANer:
     with _UPSAMPLER_LOCK:
         up = _UPSAMPLERS.get(key)
         if up is None:
-            engine = RRDBNetEngine(num_block, netscale, config.dtype, config.gpu_id)
-            engine.load_state_dict(_load_checkpoint(config, num_block, netscale))
+            state = _load_checkpoint(config, num_block, netscale)
+            from . import srvgg
+            if config.model_name in srvgg.SRVGG_MODELS and srvgg.is_srvgg_state_dict(state):
+                # the published realesr-animevideov3 / realesr-general-x4v3 checkpoints are SRVGGNetCompact, not the
+                # RRDBNet the reference declares for them (pytorch_realesrgan.py:119-128)
+                num_conv, netscale = srvgg.SRVGG_MODELS[config.model_name]
+                engine = srvgg.SRVGGNetEngine(num_conv, netscale, config.dtype, config.gpu_id)
+            else:
+                engine = RRDBNetEngine(num_block, netscale, config.dtype, config.gpu_id)
+            engine.load_state_dict(state)
             up = HipRealESRGANer(netscale, engine, tile, config.tile_pad, config.pre_pad, config.half_precision,
                                  config.gpu_id)
             _UPSAMPLERS[key] = up
