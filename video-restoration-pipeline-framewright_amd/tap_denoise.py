@@ -291,6 +291,13 @@ class TAPDenoiser:
         """In-memory form of the hot loop (tap_denoise.py:603-618): temporal window + strength blend for every frame
         (or the indices in ``only``).  ``halo_before`` / ``halo_after`` are already DENOISED uint8 neighbour frames
         owned by adjacent ranks (multi-GPU block partition); clip ends clamp like :510-511."""
+        out = self.denoise_clip_device(frames, only=only, halo_before=halo_before, halo_after=halo_after)
+        return [None if d is None else d.cpu().numpy() for d in out]
+
+    def denoise_clip_device(self, frames: Sequence, only: Optional[Sequence[int]] = None, halo_before: Sequence = (),
+                            halo_after: Sequence = ()) -> List:
+        """``denoise_clip`` with the results left in HBM (uint8 CUDA tensors): the stage hand-off of SURVEY.md §8(f) item 1.
+        ``frames`` / halos may be numpy arrays (uploaded on first use) or uint8 CUDA tensors."""
         import torch
         self._load_model()
         dev = torch.device("cuda", self.config.gpu_id)
@@ -298,17 +305,22 @@ class TAPDenoiser:
         hb, ha = len(halo_before), len(halo_after)
         cache: Dict[int, object] = {}
 
+        def up(a):
+            if isinstance(a, np.ndarray):
+                return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            return a.contiguous()
+
         def den(i):  # global index in [-hb, n + ha)
             if i not in cache:
                 if i < 0:
-                    cache[i] = torch.from_numpy(np.ascontiguousarray(halo_before[hb + i])).to(dev)
+                    cache[i] = up(halo_before[hb + i])
                 elif i >= n:
-                    cache[i] = torch.from_numpy(np.ascontiguousarray(halo_after[i - n])).to(dev)
+                    cache[i] = up(halo_after[i - n])
                 else:
-                    cache[i] = self._denoise_frame_tiled_device(torch.from_numpy(np.ascontiguousarray(frames[i])).to(dev))
+                    cache[i] = self._denoise_frame_tiled_device(up(frames[i]))
             return cache[i]
 
-        out: List[Optional[np.ndarray]] = []
+        out: List = []
         half = self.config.temporal_window // 2
         for i in (range(n) if only is None else only):
             if frames[i] is None:
@@ -323,8 +335,8 @@ class TAPDenoiser:
                 tot = sum(ws)
                 d = self._temporal_average_device([den(j) for j in idx], [x / tot for x in ws])
             if self.config.strength < 1.0:
-                d = self._strength_blend_device(torch.from_numpy(np.ascontiguousarray(frames[i])).to(dev), d)
-            out.append(d.cpu().numpy())
+                d = self._strength_blend_device(up(frames[i]), d)
+            out.append(d)
             for j in [k for k in cache if k < i - half]:  # frames that no later window needs
                 del cache[j]
         return out
