@@ -158,7 +158,19 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_kern
 
     // tiles w0, w0+1 (+bias already inside) -> LeakyReLU -> typed -> tile in LDS at `xa` (halo format, zero outside the image
     // when `zero_outside`), then the wave copies its own rows' valid interior to the global plane with 16-B/lane stores.
-    auto emit = [&](int w0, uint4* xa, int oy, int ox, T* plane, bool zero_outside) {
+    // INTERIOR (compile time): the whole compute region lies inside the image, so no per-pixel image tests are needed -
+    // true for all but the border tiles (the emit phase is VALU-bound: two waves per SIMD convert at the same time).
+    // copy-out lane plan: 64 lanes = 16 pixels x 4 physical slots, two passes per row; pixels 0 and 31 of the region are
+    // the recompute ring, never stored
+    const int co_k = lane & 3;
+    bool co_ok[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int cp = it * 16 + (lane >> 2);
+        co_ok[it] = cp >= 1 && cp <= PAIR_TW;
+    }
+    auto emit = [&](int w0, uint4* xa, int oy, int ox, T* plane, bool zero_outside, auto interior_tag) {
+        constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
         for (int row = 0; row < RPW; ++row) {
             const int cr = RPW * wave + row;  // row inside the compute region
@@ -167,13 +179,12 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_kern
             for (int ph = 0; ph < 2; ++ph) {
                 const int cp = 16 * ph + q;   // pixel inside the compute region
                 const int gx = ox + cp;
-                const bool inside = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+                const bool zero = !INTERIOR && zero_outside && !((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W);
 #pragma unroll
                 for (int wl2 = 0; wl2 < 2; ++wl2) {
                     const f32x4 v = w0 ? acc[row][2 + wl2][ph] : acc[row][wl2][ph];
-                    float o[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (zero_outside && !inside) ? 0.f : fmaxf(v[j], 0.2f * v[j]);
+                    f32x4 o = __builtin_elementwise_max(v, v * 0.2f);
+                    if (!INTERIOR && zero) o = f32x4{0.f, 0.f, 0.f, 0.f};
                     // channels 16*wl2 + 4*sl + j: slot 2*wl2 + (sl >> 1), bytes 8*(sl & 1)..
                     const int hp = cp + 1;
                     char* dst = reinterpret_cast<char*>(xa + ((cr + 1) * HALO_W + hp) * 4 + ((2 * wl2 + (sl >> 1)) ^ halo_swz(hp))) +
@@ -182,21 +193,21 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_kern
                 }
             }
         }
-        // copy-out: 64 lanes = 16 pixels x 4 physical slots; logical slot = physical ^ swizzle(px)
+        // copy-out: logical slot = physical ^ swizzle(px)
 #pragma unroll
         for (int row = 0; row < RPW; ++row) {
             const int cr = RPW * wave + row;
             const int gy = oy + cr;
+            const bool row_ok = cr >= 1 && cr <= PAIR_TH && (INTERIOR || (unsigned)gy < (unsigned)p.H);  // wave-uniform
+            if (!row_ok) continue;
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const int cp = it * 16 + (lane >> 2);  // pixel inside the compute region
-                const int k = lane & 3;
                 const int hp = cp + 1;                  // halo-tile pixel
-                const uint4 v = xa[((cr + 1) * HALO_W + hp) * 4 + k];
-                const int s = k ^ halo_swz(hp);
+                const uint4 v = xa[((cr + 1) * HALO_W + hp) * 4 + co_k];
+                const int s = co_k ^ halo_swz(hp);
                 const int gx = ox + cp;
-                if (cr >= 1 && cr <= PAIR_TH && cp >= 1 && cp <= PAIR_TW && (unsigned)gy < (unsigned)p.H &&
-                    (unsigned)gx < (unsigned)p.W)
+                if (co_ok[it] && (INTERIOR || (unsigned)gx < (unsigned)p.W))
                     *reinterpret_cast<uint4*>(plane + ((size_t)gy * p.W + gx) * p.out_cstride + s * 8) = v;
             }
         }
@@ -274,14 +285,30 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_kern
         // conv_a done.  Every wave must be finished with the last chunk's stage before it becomes the x_a tile.
         __syncthreads();
         FW_STAMP(0);
-        if (!(FW_PAIR_DBG & 4)) emit(0, lds + ((qd - 1) & 1) * ACT_REGION, oy, ox, reinterpret_cast<T*>(p.out_a), true);
+        // the whole 16x32 compute region inside the image?  (uniform; false only for border tiles)
+#ifdef FW_EMIT_NO_FASTPATH  // A/B switch
+        const bool interior = false;
+#else
+        const bool interior = oy >= 0 && ox >= 0 && oy + TILE_H <= p.H && ox + TILE_W <= p.W;
+#endif
+        if (!(FW_PAIR_DBG & 4)) {
+            if (interior)
+                emit(0, lds + ((qd - 1) & 1) * ACT_REGION, oy, ox, reinterpret_cast<T*>(p.out_a), true, std::true_type{});
+            else
+                emit(0, lds + ((qd - 1) & 1) * ACT_REGION, oy, ox, reinterpret_cast<T*>(p.out_a), true, std::false_type{});
+        }
         FW_STAMP(3);  // emit of x_a
         run_item(na, std::false_type{});
         FW_STAMP(2);  // x_a item compute
         // conv_b done: every wave has finished reading the x_a tile before it is reused as the store-transpose buffer
         __syncthreads();
         FW_STAMP(0);
-        if (!(FW_PAIR_DBG & 4)) emit(2, lds + ((qd - 1) & 1) * ACT_REGION, oy, ox, reinterpret_cast<T*>(p.out_b), false);
+        if (!(FW_PAIR_DBG & 4)) {
+            if (interior)
+                emit(2, lds + ((qd - 1) & 1) * ACT_REGION, oy, ox, reinterpret_cast<T*>(p.out_b), false, std::true_type{});
+            else
+                emit(2, lds + ((qd - 1) & 1) * ACT_REGION, oy, ox, reinterpret_cast<T*>(p.out_b), false, std::false_type{});
+        }
         FW_STAMP(3);
     }
     FW_STAMP_FLUSH(p.stamps);
