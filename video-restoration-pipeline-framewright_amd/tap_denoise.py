@@ -109,6 +109,7 @@ class NAFNetEngine:
             state = state["params"]  # type: ignore[assignment]
         elif "state_dict" in state:
             state = state["state_dict"]  # type: ignore[assignment]
+        kept = {}
         for key, shape in nafnet_tensor_shapes(**self.args):
             if key not in state:
                 raise FramewrightHipError(_lib.FW_ERR_INVALID, f"state dict is missing {key}")
@@ -116,7 +117,18 @@ class NAFNetEngine:
             if tuple(a.shape) != tuple(shape):
                 raise FramewrightHipError(_lib.FW_ERR_INVALID, f"{key}: expected shape {shape}, got {a.shape}")
             _lib.check(self._lib.fw_nafnet_set_tensor(self._h, key.encode(), C.c_void_p(a.ctypes.data), a.size))
+            kept[key] = a
         _lib.check(self._lib.fw_nafnet_finalize(self._h))
+        self._state = kept
+
+    def clone(self) -> "NAFNetEngine":
+        """A second handle with the same weights and its own workspace, so that two forwards can be in flight on two
+        streams (the tiled TAP path runs several tiles concurrently)."""
+        if getattr(self, "_state", None) is None:
+            raise FramewrightHipError(_lib.FW_ERR_INVALID, "NAFNetEngine.clone: no weights loaded")
+        e = NAFNetEngine(dtype=self.dtype, device_id=self.device_id, **self.args)
+        e.load_state_dict(self._state)
+        return e
 
     def denoise(self, frame_bgr: np.ndarray) -> np.ndarray:
         f = np.ascontiguousarray(frame_bgr)
@@ -247,17 +259,63 @@ class TAPDenoiser:
             raise ValueError(f"frame {w}x{h} is smaller than tile_size {ts} in one dimension")
         acc = torch.zeros((h, w, 3), dtype=torch.float32, device=frame.device)
         wsum = torch.zeros((h, w), dtype=torch.float32, device=frame.device)
-        tile = torch.empty((ts, ts, 3), dtype=torch.uint8, device=frame.device)
-        tout = torch.empty_like(tile)
-        st = self._stream()
+        tiles = tile_grid(h, w, ts, ov)
+        # A 512x512 tile fills a fraction of the chip (the deep levels are 32x32 pixels), so up to TILE_STREAMS tiles run
+        # concurrently, each on its own stream with its own engine clone (= its own workspace).  The ramp-blend
+        # accumulation stays on the caller's stream in tile order: float adds in the reference's order, bit for bit.
+        k = max(1, min(len(tiles), self.TILE_STREAMS))
+        workers = self._tile_workers(k, frame.device, ts)
+        main = torch.cuda.current_stream(frame.device)
         p = lambda t: C.c_void_p(t.data_ptr())
-        for y1, x1 in tile_grid(h, w, ts, ov):
-            _lib.check(lib.fw_u8_crop(p(frame), h, w, y1, x1, ts, ts, p(tile), st))
-            self._engine.denoise_device(tile, out=tout)
-            _lib.check(lib.fw_tile_blend_accumulate(p(acc), p(wsum), h, w, p(tout), y1, x1, ts, ts, ov, st))
+        start = torch.cuda.Event()
+        start.record(main)           # the frame (and acc / wsum) are ready once the caller's stream gets here
+        done = [None] * len(tiles)
+        for i, (y1, x1) in enumerate(tiles):
+            wk = workers[i % k]
+            stw = wk["stream"]
+            stw.wait_event(start if wk["free"] is None else wk["free"])
+            sp = C.c_void_p(stw.cuda_stream)
+            _lib.check(lib.fw_u8_crop(p(frame), h, w, y1, x1, ts, ts, p(wk["tile"]), sp))
+            wk["engine"].denoise_device(wk["tile"], out=wk["out"], stream=stw.cuda_stream)
+            done[i] = torch.cuda.Event()
+            done[i].record(stw)
+            # consume in order as soon as this worker's slot is needed again (or at the end)
+            if i >= k - 1:
+                j = i - (k - 1)
+                self._blend_tile(lib, main, done[j], workers[j % k], acc, wsum, h, w, tiles[j], ts, ov)
+        for j in range(max(0, len(tiles) - (k - 1)), len(tiles)):
+            self._blend_tile(lib, main, done[j], workers[j % k], acc, wsum, h, w, tiles[j], ts, ov)
+        for wk in workers:
+            wk["free"] = None        # the next frame starts from the caller's stream again
         out = torch.empty_like(frame)
-        _lib.check(lib.fw_tile_blend_finish(p(acc), p(wsum), h, w, p(out), st))
+        _lib.check(lib.fw_tile_blend_finish(p(acc), p(wsum), h, w, p(out), C.c_void_p(main.cuda_stream)))
         return out
+
+    TILE_STREAMS = int(os.environ.get("FW_TAP_TILE_STREAMS", "6"))
+
+    def _tile_workers(self, k: int, device, ts: int):
+        import torch
+        ws = getattr(self, "_workers", None)
+        if ws is None:
+            ws = self._workers = []
+        while len(ws) < k:
+            eng = self._engine if not ws else self._engine.clone()
+            ws.append({"engine": eng, "stream": torch.cuda.Stream(device=device), "free": None, "tile": None, "out": None})
+        for wk in ws[:k]:
+            if wk["tile"] is None or wk["tile"].shape[0] != ts:
+                wk["tile"] = torch.empty((ts, ts, 3), dtype=torch.uint8, device=device)
+                wk["out"] = torch.empty_like(wk["tile"])
+        return ws[:k]
+
+    @staticmethod
+    def _blend_tile(lib, main, done_ev, wk, acc, wsum, h, w, origin, ts, ov):
+        import torch
+        main.wait_event(done_ev)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        _lib.check(lib.fw_tile_blend_accumulate(p(acc), p(wsum), h, w, p(wk["out"]), origin[0], origin[1], ts, ts, ov,
+                                                C.c_void_p(main.cuda_stream)))
+        wk["free"] = torch.cuda.Event()
+        wk["free"].record(main)      # the worker may overwrite its tile buffers after this point
 
     def _temporal_average_device(self, denoised: Sequence, weights: Sequence[float]):
         import torch
@@ -417,6 +475,10 @@ class TAPDenoiser:
         return result
 
     def clear_cache(self) -> None:
+        for wk in getattr(self, "_workers", None) or []:
+            if wk["engine"] is not self._engine:
+                wk["engine"].close()
+        self._workers = None
         if self._engine is not None:
             self._engine.close()
             self._engine = None
