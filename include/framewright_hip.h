@@ -217,6 +217,56 @@ int fw_strength_blend_u8(const uint8_t* original, const uint8_t* denoised, doubl
                          void* stream);
 
 /* -------------------------------------------------------------------------------------------------
+ * Restormer building blocks (the reference's DEFAULT TAP model)
+ * replaces  `Restormer(dim=48, num_blocks=[4,6,6,8], num_refinement_blocks=4, heads=[1,2,4,8],
+ *           ffn_expansion_factor=2.66, bias=False, LayerNorm_type='WithBias')` + `self._model(tensor)`
+ *           (processors/tap_denoise.py:299-333, 458); architecture per SURVEY.md §A.4; host sequencing
+ *           framewright_amd/restormer.py.  Device pointers; the residual stream is fp32 NHWC with a padded channel stride.
+ * ------------------------------------------------------------------------------------------------- */
+
+/* LayerNorm over the first `channels` of each pixel, (x - mean) / sqrt(var + eps) * weight + bias (bias may be NULL),
+ * fp32 [pixels][x_stride] -> operand-typed [pixels][out_stride]; output channels [channels, zero_to) are zeroed. */
+int fw_layernorm_nhwc(int dtype, const float* x, long x_stride, long pixels, int channels, const float* weight,
+                      const float* bias, float eps, void* out, long out_stride, int zero_to, void* stream);
+
+/* 1x1 convolution as an MFMA GEMM.  fw_pack_pointwise packs weight [cout][k] (fp32, host; k % 32 == 0) into fragments
+ * (returns the uint16 count, dst may be NULL to query).  a: operand-typed or fp32 [pixels][a_stride]; outputs: typed
+ * and/or fp32, 32*cout_tiles channels; with res_f32: out_f32 = res_f32 + (acc + bias) * chan_scale (same stride). */
+size_t fw_pack_pointwise(int dtype, const float* weight, int cout, int k, void* dst);
+int fw_pointwise_nhwc(int dtype, const void* a, int a_is_f32, long a_stride, long pixels, int k, const void* packed_weight,
+                      const float* bias, int cout_tiles, void* out_typed, long out_stride, float* out_f32, long f32_stride,
+                      const float* res_f32, const float* chan_scale, void* stream);
+
+/* Depthwise 3x3, zero padding, no bias, weight fp32 [channels][9].  mode 0: plain; mode 1: the GDFN gate,
+ * out[c] = gelu(dw(x)[c]) * dw(x)[channels/2 + c] for c < channels/2 (exact erf GELU). */
+int fw_dwconv3x3_nhwc(int dtype, const void* x, long x_stride, int height, int width, int channels, const float* weight,
+                      int mode, void* out, long out_stride, void* stream);
+
+/* MDTA "transposed" attention.  qkv: operand-typed [pixels][stride], q at channel 0, k at k_off, v at v_off, heads*ch
+ * channels each (ch = 48 or 96).  fw_attn_matrix: attn[head][c1][c2] = softmax_c2(normalize(q)_c1 . normalize(k)_c2 *
+ * temperature[head]) with the dot products over all pixels (deterministic two-level reduction; workspace of
+ * fw_attn_workspace_floats floats).  fw_attn_apply: out[p][head*ch + c1] = sum_c2 attn[head][c1][c2] * v[p][head*ch + c2]. */
+size_t fw_attn_workspace_floats(int heads, int ch);
+int fw_attn_matrix(int dtype, const void* qkv, long stride, long pixels, int k_off, int heads, int ch,
+                   const float* temperature, float* workspace, float* attn, void* stream);
+int fw_attn_apply(int dtype, const void* qkv, long stride, long pixels, int v_off, int heads, int ch, const float* attn,
+                  void* out, long out_stride, int zero_to, void* stream);
+
+/* torch.nn.PixelShuffle(2) (unshuffle = 0) / PixelUnshuffle(2) (unshuffle = 1) on fp32 NHWC; low_h x low_w is the
+ * low-resolution size, `channels` the channel count at HIGH resolution; dst channels start at dst_coff. */
+int fw_pixel_shuffle2_f32(const float* src, long src_stride, int low_h, int low_w, int channels, float* dst,
+                          long dst_stride, int dst_coff, int unshuffle, void* stream);
+/* dst[p][dst_coff + c] = src[p][c], c < channels (torch.cat along channels). */
+int fw_copy_channels_f32(const float* src, long src_stride, long pixels, int channels, float* dst, long dst_stride,
+                         int dst_coff, void* stream);
+/* fp32 [pixels][channels] (channels % 32 == 0) -> operand-typed chunk-planar [channels/32][pixels][32]. */
+int fw_f32_to_planar(int dtype, const float* x, long pixels, int channels, void* out, void* stream);
+/* out = clip((rgb + input/255) * 255, 0, 255).astype(uint8), RGB -> BGR (tap_denoise.py:399-415: truncation); rgb is fp32
+ * [H][padded_w][rgb_cstride] with R,G,B in channels 0..2. */
+int fw_tap_post_u8(const uint8_t* in_bgr, const float* rgb, int height, int width, int padded_width, int rgb_cstride,
+                   uint8_t* out_bgr, float* out_rgb_f32, void* stream);
+
+/* -------------------------------------------------------------------------------------------------
  * RIFE frame interpolation: IFNet v4.6 building blocks (device pointers, fp32 NHWC small-channel tensors)
  * replaces  the arithmetic inside the external binary the reference shells out to,
  *           `rife-ncnn-vulkan -m rife-v4.6` (processors/interpolation.py:628-650); architecture per SURVEY.md §A.5.

@@ -109,7 +109,7 @@ def test_clip_driver_matches_reference_schedule(hip_lib):
     sd = synthetic_nafnet_state(seed=11, **args)
     eng = T.NAFNetEngine(dtype="f16", **args)
     eng.load_state_dict(sd)
-    cfg = T.TAPDenoiseConfig(temporal_window=5, strength=0.8, tile_size=48, tile_overlap=8)
+    cfg = T.TAPDenoiseConfig(model="nafnet", temporal_window=5, strength=0.8, tile_size=48, tile_overlap=8)
     dn = T.TAPDenoiser(cfg, engine=eng)
     frames = list(synthetic_frames(6, 72, 100, seed=5))
     got = dn.denoise_clip(frames)
@@ -137,7 +137,7 @@ def test_denoise_frames_directory_contract(hip_lib, tmp_path, monkeypatch):
     for i, f in enumerate(synthetic_frames(3, 48, 64, seed=9)):
         Image.fromarray(f[:, :, ::-1]).save(src / f"frame_{i + 1:08d}.png")
     seen = []
-    dn = T.TAPDenoiser(T.TAPDenoiseConfig(tile_size=0, temporal_window=3), model_dir=tmp_path / "none")
+    dn = T.TAPDenoiser(T.TAPDenoiseConfig(model="nafnet", tile_size=0, temporal_window=3), model_dir=tmp_path / "none")
     res = dn.denoise_frames(src, dst, progress_callback=seen.append)
     assert res.frames_processed == 3 and res.frames_failed == 0 and res.output_dir == dst
     assert sorted(p.name for p in dst.glob("*.png")) == [f"frame_{i:08d}.png" for i in (1, 2, 3)]

@@ -58,5 +58,6 @@ def test_oracle_truncates_like_the_reference():
 
 
 def test_unaccelerated_models_are_reported_unavailable():
-    d = T.TAPDenoiser(T.TAPDenoiseConfig(model=T.TAPModel.RESTORMER))
+    assert T.TAPDenoiseConfig().model is T.TAPModel.RESTORMER          # the reference's default (tap_denoise.py:110)
+    d = T.TAPDenoiser(T.TAPDenoiseConfig(model=T.TAPModel.TAP))
     assert d.is_available() is False

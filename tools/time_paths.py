@@ -21,11 +21,17 @@ eng = T.NAFNetEngine(dtype="f16", **T.NAFNET_ARGS); eng.load_state_dict(syntheti
 out = torch.empty_like(dev[0])
 res["nafnet_1080p_whole_frame_ms"] = timed(lambda: eng.denoise_device(dev[0], out=out))
 res["nafnet_1080p_tflop"] = eng.flops(1080, 1920) / 1e12
-dn = T.TAPDenoiser(T.TAPDenoiseConfig(tile_size=512, tile_overlap=32), engine=eng)
+dn = T.TAPDenoiser(T.TAPDenoiseConfig(model="nafnet", tile_size=512, tile_overlap=32), engine=eng)
 res["tap_1080p_tiled512_per_frame_ms"] = timed(lambda: dn._denoise_frame_tiled_device(dev[0]))
 tile = torch.from_numpy(np.ascontiguousarray(frames[0][:512, :512])).cuda(); tout = torch.empty_like(tile)
 res["nafnet_512_tile_ms"] = timed(lambda: eng.denoise_device(tile, out=tout), n=5)
 eng.close()
+from framewright_amd import restormer as RS
+re_ = RS.RestormerEngine(dtype="f16", **RS.RESTORMER_ARGS); re_.load_state_dict(RS.synthetic_restormer_state(**RS.RESTORMER_ARGS))
+res["restormer_512_tile_ms"] = timed(lambda: re_.denoise_device(tile, out=tout), n=3)
+dr = T.TAPDenoiser(T.TAPDenoiseConfig(tile_size=512, tile_overlap=32), engine=re_)
+res["tap_restormer_1080p_tiled512_per_frame_ms"] = timed(lambda: dr._denoise_frame_tiled_device(dev[0]), n=2)
+re_.close()
 ie = RF.IFNetEngine("f16"); ie.load_state_dict(synthetic_ifnet_state())
 o2 = torch.empty_like(dev[0])
 res["rife_1080p_pair_ms"] = timed(lambda: ie.interpolate_device(dev[0], dev[1], out=o2))

@@ -31,6 +31,8 @@ EXPORTS = [
     "fw_conv3x3_nhwc_ex", "fw_conv3x3_pair_nhwc", "fw_u8_to_rgb_f32", "fw_resize_bilinear_f32", "fw_ifnet_build_x", "fw_unshuffle2_cast",
     "fw_depth_to_space4_f32", "fw_ifnet_accumulate", "fw_ifnet_blend",
     "fw_u8_to_nhwc", "fw_pixel_shuffle_add_u8",
+    "fw_layernorm_nhwc", "fw_pack_pointwise", "fw_pointwise_nhwc", "fw_dwconv3x3_nhwc", "fw_attn_workspace_floats",
+    "fw_attn_matrix", "fw_attn_apply", "fw_pixel_shuffle2_f32", "fw_copy_channels_f32", "fw_f32_to_planar", "fw_tap_post_u8",
 ]
 
 
@@ -110,7 +112,7 @@ def _declare_tap(lib: C.CDLL) -> None:
 
 
 def _declare_ifnet(lib: C.CDLL) -> None:
-    vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
+    vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
     lib.fw_conv3x3_nhwc_ex.restype = i32
     lib.fw_conv3x3_nhwc_ex.argtypes = [i32, vp, i32, C.c_long, i32, i32, i32, vp, vp, i32, i32, i32, vp, f32, vp, f32, vp, i32,
                                        i32, i32, vp, i32, C.c_long, i32, vp, vp]
@@ -134,6 +136,29 @@ def _declare_ifnet(lib: C.CDLL) -> None:
     lib.fw_u8_to_nhwc.argtypes = [i32, vp, i32, i32, vp, i32, vp]
     lib.fw_pixel_shuffle_add_u8.restype = i32
     lib.fw_pixel_shuffle_add_u8.argtypes = [vp, i32, vp, i32, i32, i32, vp, vp, vp]
+    i64 = C.c_long
+    lib.fw_layernorm_nhwc.restype = i32
+    lib.fw_layernorm_nhwc.argtypes = [i32, vp, i64, i64, i32, vp, vp, f32, vp, i64, i32, vp]
+    lib.fw_pack_pointwise.restype = sz
+    lib.fw_pack_pointwise.argtypes = [i32, vp, i32, i32, vp]
+    lib.fw_pointwise_nhwc.restype = i32
+    lib.fw_pointwise_nhwc.argtypes = [i32, vp, i32, i64, i64, i32, vp, vp, i32, vp, i64, vp, i64, vp, vp, vp]
+    lib.fw_dwconv3x3_nhwc.restype = i32
+    lib.fw_dwconv3x3_nhwc.argtypes = [i32, vp, i64, i32, i32, i32, vp, i32, vp, i64, vp]
+    lib.fw_attn_workspace_floats.restype = sz
+    lib.fw_attn_workspace_floats.argtypes = [i32, i32]
+    lib.fw_attn_matrix.restype = i32
+    lib.fw_attn_matrix.argtypes = [i32, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp]
+    lib.fw_attn_apply.restype = i32
+    lib.fw_attn_apply.argtypes = [i32, vp, i64, i64, i32, i32, i32, vp, vp, i64, i32, vp]
+    lib.fw_pixel_shuffle2_f32.restype = i32
+    lib.fw_pixel_shuffle2_f32.argtypes = [vp, i64, i32, i32, i32, vp, i64, i32, i32, vp]
+    lib.fw_copy_channels_f32.restype = i32
+    lib.fw_copy_channels_f32.argtypes = [vp, i64, i64, i32, vp, i64, i32, vp]
+    lib.fw_f32_to_planar.restype = i32
+    lib.fw_f32_to_planar.argtypes = [i32, vp, i64, i32, vp, vp]
+    lib.fw_tap_post_u8.restype = i32
+    lib.fw_tap_post_u8.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
 
 
 def load() -> C.CDLL:

@@ -169,12 +169,12 @@ void launch_u8_to_nhwc_padded(DType dt, const uint8_t* in_bgr, int H, int W, int
 // out = ending(x) + inp, crop to H x W, then tap_denoise.py:399-415: np.clip(x * 255.0, 0, 255).astype(uint8)
 // (TRUNCATION, not rounding), RGB -> BGR.
 __global__ __launch_bounds__(256) void tap_post_kernel(const uint8_t* __restrict__ in_bgr, const float* __restrict__ rgb,
-                                                       int H, int W, int Wp, uint8_t* out_bgr, float* out_rgb) {
+                                                       int H, int W, int Wp, int cs, uint8_t* out_bgr, float* out_rgb) {
     const long n = (long)H * W;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int y = (int)(i / W), x = (int)(i - (long)y * W);
         const uint8_t* px = in_bgr + (size_t)i * 3;
-        const float* r = rgb + ((size_t)y * Wp + x) * 3;
+        const float* r = rgb + ((size_t)y * Wp + x) * cs;
         float v[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) v[c] = r[c] + px[2 - c] / 255.0f;
@@ -189,11 +189,11 @@ __global__ __launch_bounds__(256) void tap_post_kernel(const uint8_t* __restrict
     }
 }
 
-void launch_tap_post(const uint8_t* in_bgr, const float* rgb, int H, int W, int Wp, uint8_t* out_bgr, float* out_rgb,
+void launch_tap_post(const uint8_t* in_bgr, const float* rgb, int H, int W, int Wp, int cs, uint8_t* out_bgr, float* out_rgb,
                      hipStream_t st) {
     const long n = (long)H * W;
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    hipLaunchKernelGGL(tap_post_kernel, dim3(blocks), dim3(256), 0, st, in_bgr, rgb, H, W, Wp, out_bgr, out_rgb);
+    hipLaunchKernelGGL(tap_post_kernel, dim3(blocks), dim3(256), 0, st, in_bgr, rgb, H, W, Wp, cs, out_bgr, out_rgb);
     FW_HIP_CHECK(hipGetLastError());
 }
 

@@ -154,8 +154,8 @@ void launch_f32_to_planar(DType dt, const float* x, long M, int C, void* out, hi
 
 // ---- TAP frame path + K8 blend kernels (frame_ops.hip) ---------------------------------------------------
 void launch_u8_to_nhwc_padded(DType dt, const uint8_t* in_bgr, int H, int W, int Hp, int Wp, void* out, hipStream_t st);
-void launch_tap_post(const uint8_t* in_bgr, const float* rgb, int H, int W, int Wp, uint8_t* out_bgr, float* out_rgb,
-                     hipStream_t st);
+void launch_tap_post(const uint8_t* in_bgr, const float* rgb, int H, int W, int Wp, int rgb_cstride, uint8_t* out_bgr,
+                     float* out_rgb, hipStream_t st);
 void launch_u8_crop(const uint8_t* src, int W, int y0, int x0, int th, int tw, uint8_t* dst, hipStream_t st);
 void launch_tile_blend_acc(float* acc, float* wsum, int W, const uint8_t* tile, int y0, int x0, int th, int tw, int ov,
                            int top, int bottom, int left, int right, hipStream_t st);

@@ -285,7 +285,7 @@ void forward(fw_nafnet* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, fl
         p.img_W = Wp; p.s1 = p.s2 = 1.f;
         launch_conv3x3(n->dt, 1, EPI_IMAGE, p, st);
     }
-    launch_tap_post(d_in, (const float*)(ws + pl.rgb), H, W, Wp, d_out, d_rgb, st);
+    launch_tap_post(d_in, (const float*)(ws + pl.rgb), H, W, Wp, 3, d_out, d_rgb, st);
 }
 
 }  // namespace

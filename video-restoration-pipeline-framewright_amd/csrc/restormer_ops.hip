@@ -1,0 +1,500 @@
+// Building blocks of Restormer (the reference's default TAP model: `_load_restormer`,
+// src/framewright/processors/tap_denoise.py:299-333, `Restormer(dim=48, num_blocks=[4,6,6,8], num_refinement_blocks=4,
+// heads=[1,2,4,8], ffn_expansion_factor=2.66, bias=False, LayerNorm_type='WithBias')`; the network itself is third-party
+// `basicsr.archs.restormer_arch`, absent from the reference tree — architecture per SURVEY.md §A.4, oracle
+// oracle/restormer_ref.py, parity unpinned).  Host sequencing: framewright_amd/restormer.py.
+//
+// Layout: the residual stream is fp32 NHWC with a padded channel stride; everything that feeds an MFMA (1x1 convs through
+// pointwise_mfma_kernel, 3x3 convs through conv3x3_mfma_kernel) is operand-typed with channels padded to 32.
+//   layernorm_nhwc       per-pixel LayerNorm over the first C channels ('WithBias': (x-mu)/sqrt(var+eps)*w+b), typed out
+//   dwconv3x3_nhwc       depthwise 3x3 (no bias); mode 1 fuses the GDFN gate gelu(x1)*x2
+//   attn_gram / finish   MDTA "transposed" attention: per head the c x c Gram matrix of L2-normalised q, k over all pixels
+//                        (fixed-order two-level reduction -> deterministic), temperature, softmax
+//   attn_apply           out[p][c1] = sum_c2 A[head][c1][c2] * v[p][c2]
+//   pixel_(un)shuffle2   fp32 NHWC
+#include "fw_internal.h"
+#include "../../include/framewright_hip.h"
+
+namespace fw {
+
+typedef __bf16 rbf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 rf16x8 __attribute__((ext_vector_type(8)));
+template <typename T> struct V8;
+template <> struct V8<__bf16> { using t = rbf16x8; };
+template <> struct V8<_Float16> { using t = rf16x8; };
+
+// ---- LayerNorm over channels, fp32 [M][ldx] -> typed [M][ldo]; channels [C, Cz) of the output are zeroed ---------------
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_nhwc_kernel(const float* __restrict__ x, long ldx, long M, int C,
+                                                             const float* __restrict__ w, const float* __restrict__ b,
+                                                             float eps, T* out, long ldo, int Cz) {
+    const int lane = threadIdx.x & 63;
+    const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long m = wave0; m < M; m += nwaves) {
+        const float* row = x + m * ldx;
+        float v[8];  // C <= 512
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < C ? row[c] : 0.f;
+            s += v[i];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mu = s / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + 64 * i;
+            const float d = c < C ? v[i] - mu : 0.f;
+            q += d * d;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+        T* orow = out + m * ldo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + 64 * i;
+            if (c < C)
+                orow[c] = (T)((v[i] - mu) * rstd * w[c] + (b ? b[c] : 0.f));
+            else if (c < Cz)
+                orow[c] = (T)0.f;
+        }
+    }
+}
+
+// ---- depthwise 3x3, zero padding, typed [H][W][ldx] -> typed [H][W][ldo] -------------------------------------------------
+// mode 0: out[c] = dw(x)[c], c < C.   mode 1: out[c] = gelu(dw(x)[c]) * dw(x)[C/2 + c], c < C/2 (exact erf GELU).
+// wdw: fp32 [C][9].  C % 8 == 0.  Filters in LDS as [tap][C].
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void dwconv3x3_nhwc_kernel(const T* __restrict__ x, long ldx, int H, int W, int C,
+                                                             const float* __restrict__ wdw, T* out, long ldo) {
+    extern __shared__ __attribute__((aligned(16))) float dw_w[];
+    for (int i = threadIdx.x; i < 9 * C; i += 256) {
+        const int ch = i / 9, tap = i - ch * 9;
+        dw_w[tap * C + ch] = wdw[i];
+    }
+    __syncthreads();
+    const int Co = MODE == 1 ? C / 2 : C;
+    const int groups = Co / 8;
+    const long total = (long)H * W * groups;
+    using V = typename V8<T>::t;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long pix = idx / groups;
+        const int g = (int)(idx - pix * groups);
+        const int yy = (int)(pix / W), xx = (int)(pix - (long)yy * W);
+        float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int sy = yy + dy;
+            if (sy < 0 || sy >= H) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int sx = xx + dx;
+                if (sx < 0 || sx >= W) continue;
+                const T* src = x + ((long)sy * W + sx) * ldx;
+                const int tap = (dy + 1) * 3 + (dx + 1);
+                const V f1 = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(src + g * 8));
+                const float* w1 = dw_w + tap * C + g * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a1[j] += (float)f1[j] * w1[j];
+                if (MODE == 1) {
+                    const V f2 = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(src + Co + g * 8));
+                    const float* w2 = dw_w + tap * C + Co + g * 8;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a2[j] += (float)f2[j] * w2[j];
+                }
+            }
+        }
+        V o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float r = a1[j];
+            if (MODE == 1) r = 0.5f * r * (1.0f + erff(r * 0.70710678118654752f)) * a2[j];
+            o[j] = (T)r;
+        }
+        *reinterpret_cast<uint4*>(out + pix * ldo + g * 8) = __builtin_bit_cast(uint4, o);
+    }
+}
+
+// ---- MDTA Gram matrices ---------------------------------------------------------------------------------------------------
+// qkv typed [M][ld]: q at channel 0, k at k_off; `dim` = heads * ch channels each.  partial[block][dim*ch + 2*dim]:
+//   [h][c1][c2] = sum_p q[p][h*ch+c1] * k[p][h*ch+c2] over the block's pixels, then sum q^2 and sum k^2 per channel.
+// A thread owns 3x3 patches of (c1, c2): patch index -> (head, c1/3, c2/3); pixels are staged 16 at a time through LDS.
+constexpr int GRAM_PX = 16;
+constexpr int GRAM_MAX_BLOCKS = 512;
+template <typename T>
+__global__ __launch_bounds__(256) void attn_gram_kernel(const T* __restrict__ qkv, long ld, long M, int k_off, int heads, int ch,
+                                                        float* partial) {
+    extern __shared__ __attribute__((aligned(16))) float gq[];  // [GRAM_PX][dim] q then [GRAM_PX][dim] k
+    const int dim = heads * ch;
+    float* gk = gq + GRAM_PX * dim;
+    const int pp = ch / 3;                        // patches per side
+    const int npatch = heads * pp * pp;
+    constexpr int MAXP = 8;                       // dim*ch/9/256 <= 8 for (384,48), (96,96), (192,48), ...
+    float acc[MAXP][9];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) acc[i][j] = 0.f;
+    float nq[2] = {0.f, 0.f}, nk[2] = {0.f, 0.f};  // channels tid and tid + 256 (dim <= 512)
+    const long chunks = (M + GRAM_PX - 1) / GRAM_PX;
+    for (long cb = blockIdx.x; cb < chunks; cb += gridDim.x) {
+        const long p0 = cb * GRAM_PX;
+        __syncthreads();
+        for (int i = threadIdx.x; i < GRAM_PX * dim; i += 256) {
+            const int px = i / dim, c = i - px * dim;
+            const long p = p0 + px;
+            gq[i] = p < M ? (float)qkv[p * ld + c] : 0.f;
+            gk[i] = p < M ? (float)qkv[p * ld + k_off + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int pt = threadIdx.x + 256 * i;
+            if (pt < npatch) {
+                const int h = pt / (pp * pp), r = pt - h * pp * pp;
+                const int c1 = h * ch + 3 * (r / pp), c2 = h * ch + 3 * (r % pp);
+#pragma unroll 4
+                for (int px = 0; px < GRAM_PX; ++px) {
+                    const float q0 = gq[px * dim + c1], q1 = gq[px * dim + c1 + 1], q2 = gq[px * dim + c1 + 2];
+                    const float k0 = gk[px * dim + c2], k1 = gk[px * dim + c2 + 1], k2 = gk[px * dim + c2 + 2];
+                    acc[i][0] += q0 * k0; acc[i][1] += q0 * k1; acc[i][2] += q0 * k2;
+                    acc[i][3] += q1 * k0; acc[i][4] += q1 * k1; acc[i][5] += q1 * k2;
+                    acc[i][6] += q2 * k0; acc[i][7] += q2 * k1; acc[i][8] += q2 * k2;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = threadIdx.x + 256 * i;
+            if (c < dim)
+                for (int px = 0; px < GRAM_PX; ++px) {
+                    nq[i] += gq[px * dim + c] * gq[px * dim + c];
+                    nk[i] += gk[px * dim + c] * gk[px * dim + c];
+                }
+        }
+    }
+    float* out = partial + (size_t)blockIdx.x * (dim * ch + 2 * dim);
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        const int pt = threadIdx.x + 256 * i;
+        if (pt < npatch) {
+            const int h = pt / (pp * pp), r = pt - h * pp * pp;
+            const int c1 = 3 * (r / pp), c2 = 3 * (r % pp);
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) out[(h * ch + c1 + a) * ch + c2 + b] = acc[i][a * 3 + b];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < dim) {
+            out[dim * ch + c] = nq[i];
+            out[dim * ch + dim + c] = nk[i];
+        }
+    }
+}
+
+// Sum the partials in block order (deterministic), then A[h][c1][:] = softmax_c2(G / (|q_c1| |k_c2|) * temperature[h])
+// with F.normalize's clamp (norm >= 1e-12).  One workgroup per (head, c1) row.
+__global__ __launch_bounds__(128) void attn_finish_kernel(const float* __restrict__ partial, int nblocks, int heads, int ch,
+                                                          const float* __restrict__ temperature, float* attn) {
+    __shared__ float row[128];
+    __shared__ float red[128];
+    const int dim = heads * ch;
+    const int h = blockIdx.x / ch, c1 = blockIdx.x - h * ch;
+    const int c2 = threadIdx.x;
+    const size_t stride = (size_t)dim * ch + 2 * dim;
+    float g = 0.f, kn = 0.f, qn = 0.f;
+    if (c2 < ch) {
+        for (int b = 0; b < nblocks; ++b) {
+            const float* pb = partial + b * stride;
+            g += pb[(h * ch + c1) * ch + c2];
+            kn += pb[dim * ch + dim + h * ch + c2];
+            qn += pb[dim * ch + h * ch + c1];
+        }
+        const float dq = fmaxf(sqrtf(qn), 1e-12f), dk = fmaxf(sqrtf(kn), 1e-12f);
+        row[c2] = g / (dq * dk) * temperature[h];
+    }
+    __syncthreads();
+    red[c2] = c2 < ch ? row[c2] : -3.0e38f;
+    __syncthreads();
+    for (int o = 64; o > 0; o >>= 1) {
+        if (c2 < o) red[c2] = fmaxf(red[c2], red[c2 + o]);
+        __syncthreads();
+    }
+    const float mx = red[0];
+    __syncthreads();
+    const float e = c2 < ch ? expf(row[c2] - mx) : 0.f;
+    red[c2] = e;
+    __syncthreads();
+    for (int o = 64; o > 0; o >>= 1) {
+        if (c2 < o) red[c2] += red[c2 + o];
+        __syncthreads();
+    }
+    if (c2 < ch) attn[((size_t)h * ch + c1) * ch + c2] = e / red[0];
+}
+
+// out[p][h*ch + c1] = sum_c2 A[h][c1][c2] * v[p][v_off + h*ch + c2]; typed out, channels [dim, Cz) zeroed.
+// thread = (pixel, 8 output channels); A in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_apply_kernel(const T* __restrict__ qkv, long ld, long M, int v_off, int heads, int ch,
+                                                         const float* __restrict__ attn, T* out, long ldo, int Cz) {
+    extern __shared__ __attribute__((aligned(16))) float sa[];  // [dim][ch]
+    const int dim = heads * ch;
+    for (int i = threadIdx.x; i < dim * ch; i += 256) sa[i] = attn[i];
+    __syncthreads();
+    const int groups = Cz / 8;
+    const long total = M * groups;
+    using V = typename V8<T>::t;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long p = idx / groups;
+        const int g = (int)(idx - p * groups);
+        V o;
+        if (g * 8 >= dim) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (T)0.f;
+        } else {
+            const int h = (g * 8) / ch;             // ch % 8 == 0: a group never straddles heads
+            const T* vrow = qkv + p * ld + v_off + h * ch;
+            float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int c2 = 0; c2 < ch; c2 += 8) {
+                const V vv = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(vrow + c2));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float* ar = sa + (size_t)(g * 8 + j) * ch + c2;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) a[j] += ar[t] * (float)vv[t];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (T)a[j];
+        }
+        *reinterpret_cast<uint4*>(out + p * ldo + g * 8) = __builtin_bit_cast(uint4, o);
+    }
+}
+
+// ---- pixel (un)shuffle, fp32 NHWC -------------------------------------------------------------------------------------------
+// shuffle:   dst[2y+dy][2x+dx][coff + c] = src[y][x][c*4 + dy*2 + dx],  c < C            (torch.nn.PixelShuffle(2))
+// unshuffle: dst[y][x][coff + c*4 + dy*2 + dx] = src[2y+dy][2x+dx][c], c < C            (torch.nn.PixelUnshuffle(2))
+__global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const float* __restrict__ src, long lds_, int H, int W, int C,
+                                                             float* dst, long ldd, int coff, int unshuffle) {
+    const long total = (long)H * W * C * 4;  // H x W = the LOW-resolution size in both directions
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % (4 * C));
+        const long pl = i / (4 * C);
+        const int y = (int)(pl / W), x = (int)(pl - (long)y * W);
+        const int c = k >> 2, dy = (k >> 1) & 1, dx = k & 1;
+        const long hi = ((long)(2 * y + dy) * (2 * W) + (2 * x + dx));
+        if (unshuffle)
+            dst[pl * ldd + coff + k] = src[hi * lds_ + c];
+        else
+            dst[hi * ldd + coff + c] = src[pl * lds_ + k];
+    }
+}
+
+// fp32 [M][ldx] channels [0, C) -> [M][ldd] at coff (concat along channels)
+__global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restrict__ src, long ldx, long M, int C, float* dst,
+                                                            long ldd, int coff) {
+    const long total = M * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / C;
+        const int c = (int)(i - m * C);
+        dst[m * ldd + coff + c] = src[m * ldx + c];
+    }
+}
+
+static int blocks_for(long n, int cap) {
+    const long b = (n + 255) / 256;
+    return (int)(b < cap ? (b > 0 ? b : 1) : cap);
+}
+
+}  // namespace fw
+
+using namespace fw;
+
+namespace {
+int rfail(int code, const std::string& m) {
+    fw::last_error_ref() = m;
+    return code;
+}
+template <typename F>
+int rguard(F&& f) {
+    try {
+        f();
+        return FW_OK;
+    } catch (const fw::Error& e) {
+        return rfail(e.code, e.what());
+    } catch (const std::exception& e) {
+        return rfail(FW_ERR_INTERNAL, e.what());
+    }
+}
+bool bad_dtype(int d) { return d != FW_DTYPE_BF16 && d != FW_DTYPE_F16; }
+}  // namespace
+
+extern "C" {
+
+int fw_layernorm_nhwc(int dtype, const float* x, long ldx, long M, int C, const float* weight, const float* bias, float eps,
+                      void* out, long ldo, int zero_to, void* stream) {
+    if (bad_dtype(dtype) || !x || !weight || !out || M < 1 || C < 1 || C > 512 || zero_to > ldo || C > ldx)
+        return rfail(FW_ERR_INVALID, "fw_layernorm_nhwc: bad argument");
+    return rguard([&] {
+        const int blocks = blocks_for(M * 64, 4096);
+        if (dtype == FW_DTYPE_BF16)
+            hipLaunchKernelGGL((layernorm_nhwc_kernel<__bf16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, M, C, weight,
+                               bias, eps, (__bf16*)out, ldo, zero_to);
+        else
+            hipLaunchKernelGGL((layernorm_nhwc_kernel<_Float16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, M, C,
+                               weight, bias, eps, (_Float16*)out, ldo, zero_to);
+        FW_HIP_CHECK(hipGetLastError());
+    });
+}
+
+size_t fw_pack_pointwise(int dtype, const float* weight, int cout, int k, void* dst) {
+    if (bad_dtype(dtype) || cout < 1 || k < 1 || (k & 31)) return 0;
+    return pack_pointwise_weights((DType)dtype, weight, cout, k, (uint16_t*)dst);
+}
+
+int fw_pointwise_nhwc(int dtype, const void* a, int a_is_f32, long lda, long M, int k, const void* packed_weight,
+                      const float* bias, int cout_tiles, void* out_typed, long ldo, float* out_f32, long ldf,
+                      const float* res_f32, const float* chan_scale, void* stream) {
+    if (bad_dtype(dtype) || !a || !packed_weight || (!out_typed && !out_f32))
+        return rfail(FW_ERR_INVALID, "fw_pointwise_nhwc: bad argument");
+    if (res_f32 && (!out_f32 || !chan_scale)) return rfail(FW_ERR_INVALID, "fw_pointwise_nhwc: residual needs out_f32 and chan_scale");
+    return rguard([&] {
+        PointwiseParams p{};
+        p.a = a;
+        p.a_f32 = a_is_f32;
+        p.lda = lda;
+        p.M = M;
+        p.K = k;
+        p.wpk = packed_weight;
+        p.bias = bias;
+        p.N_tiles = cout_tiles;
+        p.mode = res_f32 ? PW_RESIDUAL : PW_STORE;
+        p.out_typed = out_typed;
+        p.ldo = ldo;
+        p.out_f32 = out_f32;
+        p.ldf = ldf;
+        p.res_f32 = res_f32;
+        p.chan_scale = chan_scale;
+        launch_pointwise((DType)dtype, p, (hipStream_t)stream);
+    });
+}
+
+int fw_dwconv3x3_nhwc(int dtype, const void* x, long ldx, int H, int W, int channels, const float* weight, int mode, void* out,
+                      long ldo, void* stream) {
+    if (bad_dtype(dtype) || !x || !weight || !out || H < 1 || W < 1 || channels < 8 || (channels & 7) || channels > 4096 ||
+        (mode != 0 && mode != 1) || (mode == 1 && (channels & 15)))
+        return rfail(FW_ERR_INVALID, "fw_dwconv3x3_nhwc: bad argument");
+    return rguard([&] {
+        const size_t smem = (size_t)9 * channels * sizeof(float);
+        static const bool attr = [] {
+            const int cap = 9 * 4096 * (int)sizeof(float);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_nhwc_kernel<__bf16, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_nhwc_kernel<__bf16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_nhwc_kernel<_Float16, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_nhwc_kernel<_Float16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            return true;
+        }();
+        (void)attr;
+        const int co = mode == 1 ? channels / 2 : channels;
+        const int blocks = blocks_for((long)H * W * (co / 8), 2048);
+        hipStream_t st = (hipStream_t)stream;
+#define FW_DW(T, MO) hipLaunchKernelGGL((dwconv3x3_nhwc_kernel<T, MO>), dim3(blocks), dim3(256), smem, st, (const T*)x, ldx, H, W, channels, weight, (T*)out, ldo)
+        if (dtype == FW_DTYPE_BF16) { if (mode) FW_DW(__bf16, 1); else FW_DW(__bf16, 0); }
+        else { if (mode) FW_DW(_Float16, 1); else FW_DW(_Float16, 0); }
+#undef FW_DW
+        FW_HIP_CHECK(hipGetLastError());
+    });
+}
+
+size_t fw_attn_workspace_floats(int heads, int ch) {
+    const size_t dim = (size_t)heads * ch;
+    return (size_t)fw::GRAM_MAX_BLOCKS * (dim * ch + 2 * dim);
+}
+
+int fw_attn_matrix(int dtype, const void* qkv, long ld, long M, int k_off, int heads, int ch, const float* temperature,
+                   float* workspace, float* attn, void* stream) {
+    const int dim = heads * ch;
+    if (bad_dtype(dtype) || !qkv || !temperature || !workspace || !attn || M < 1 || heads < 1 || (ch != 48 && ch != 96) ||
+        dim > 512 || heads * (ch / 3) * (ch / 3) > 8 * 256)
+        return rfail(FW_ERR_INVALID, "fw_attn_matrix: bad argument");
+    return rguard([&] {
+        hipStream_t st = (hipStream_t)stream;
+        const long chunks = (M + GRAM_PX - 1) / GRAM_PX;
+        const int nb = (int)(chunks < GRAM_MAX_BLOCKS ? chunks : GRAM_MAX_BLOCKS);
+        const size_t smem = (size_t)2 * GRAM_PX * dim * sizeof(float);
+        if (dtype == FW_DTYPE_BF16)
+            hipLaunchKernelGGL((attn_gram_kernel<__bf16>), dim3(nb), dim3(256), smem, st, (const __bf16*)qkv, ld, M, k_off, heads, ch, workspace);
+        else
+            hipLaunchKernelGGL((attn_gram_kernel<_Float16>), dim3(nb), dim3(256), smem, st, (const _Float16*)qkv, ld, M, k_off, heads, ch, workspace);
+        hipLaunchKernelGGL(attn_finish_kernel, dim3(heads * ch), dim3(128), 0, st, (const float*)workspace, nb, heads, ch, temperature, attn);
+        FW_HIP_CHECK(hipGetLastError());
+    });
+}
+
+int fw_attn_apply(int dtype, const void* qkv, long ld, long M, int v_off, int heads, int ch, const float* attn, void* out,
+                  long ldo, int zero_to, void* stream) {
+    const int dim = heads * ch;
+    if (bad_dtype(dtype) || !qkv || !attn || !out || M < 1 || (ch & 7) || (zero_to & 7) || zero_to < dim || zero_to > ldo)
+        return rfail(FW_ERR_INVALID, "fw_attn_apply: bad argument");
+    return rguard([&] {
+        const size_t smem = (size_t)dim * ch * sizeof(float);
+        static const bool attr = [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_apply_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_apply_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            return true;
+        }();
+        (void)attr;
+        const int blocks = blocks_for(M * (zero_to / 8), 2048);
+        hipStream_t st = (hipStream_t)stream;
+        if (dtype == FW_DTYPE_BF16)
+            hipLaunchKernelGGL((attn_apply_kernel<__bf16>), dim3(blocks), dim3(256), smem, st, (const __bf16*)qkv, ld, M, v_off, heads, ch, attn, (__bf16*)out, ldo, zero_to);
+        else
+            hipLaunchKernelGGL((attn_apply_kernel<_Float16>), dim3(blocks), dim3(256), smem, st, (const _Float16*)qkv, ld, M, v_off, heads, ch, attn, (_Float16*)out, ldo, zero_to);
+        FW_HIP_CHECK(hipGetLastError());
+    });
+}
+
+int fw_pixel_shuffle2_f32(const float* src, long src_stride, int low_h, int low_w, int channels, float* dst, long dst_stride,
+                          int dst_coff, int unshuffle, void* stream) {
+    if (!src || !dst || low_h < 1 || low_w < 1 || channels < 1) return rfail(FW_ERR_INVALID, "fw_pixel_shuffle2_f32: bad argument");
+    return rguard([&] {
+        const int blocks = blocks_for((long)low_h * low_w * channels * 4, 4096);
+        hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, src_stride, low_h, low_w,
+                           channels, dst, dst_stride, dst_coff, unshuffle);
+        FW_HIP_CHECK(hipGetLastError());
+    });
+}
+
+int fw_copy_channels_f32(const float* src, long src_stride, long M, int channels, float* dst, long dst_stride, int dst_coff,
+                         void* stream) {
+    if (!src || !dst || M < 1 || channels < 1) return rfail(FW_ERR_INVALID, "fw_copy_channels_f32: bad argument");
+    return rguard([&] {
+        hipLaunchKernelGGL(copy_channels_kernel, dim3(blocks_for(M * channels, 4096)), dim3(256), 0, (hipStream_t)stream, src,
+                           src_stride, M, channels, dst, dst_stride, dst_coff);
+        FW_HIP_CHECK(hipGetLastError());
+    });
+}
+
+int fw_f32_to_planar(int dtype, const float* x, long M, int channels, void* out, void* stream) {
+    if (bad_dtype(dtype) || !x || !out || M < 1 || channels < 32 || (channels & 31))
+        return rfail(FW_ERR_INVALID, "fw_f32_to_planar: bad argument");
+    return rguard([&] { launch_f32_to_planar((DType)dtype, x, M, channels, out, (hipStream_t)stream); });
+}
+
+int fw_tap_post_u8(const uint8_t* in_bgr, const float* rgb, int H, int W, int padded_w, int rgb_cstride, uint8_t* out_bgr,
+                   float* out_rgb_f32, void* stream) {
+    if (!in_bgr || !rgb || (!out_bgr && !out_rgb_f32) || H < 1 || W < 1 || rgb_cstride < 3)
+        return rfail(FW_ERR_INVALID, "fw_tap_post_u8: bad argument");
+    return rguard([&] { launch_tap_post(in_bgr, rgb, H, W, padded_w, rgb_cstride, out_bgr, out_rgb_f32, (hipStream_t)stream); });
+}
+
+}  // extern "C"

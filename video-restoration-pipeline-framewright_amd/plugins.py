@@ -165,7 +165,8 @@ class TAPDenoisePlugin(ProcessorPlugin):
 
     def _on_initialize(self) -> None:
         from . import tap_denoise as T
-        self._dn = T.TAPDenoiser(T.TAPDenoiseConfig(temporal_window=int(self._settings.get("temporal_window", 5)),
+        self._dn = T.TAPDenoiser(T.TAPDenoiseConfig(model=self._settings.get("model", T.TAPModel.RESTORMER),
+                                                    temporal_window=int(self._settings.get("temporal_window", 5)),
                                                     strength=float(self._settings.get("strength", 1.0)),
                                                     tile_size=int(self._settings.get("tile_size", 512)),
                                                     gpu_id=_gpu_id(self._device)))

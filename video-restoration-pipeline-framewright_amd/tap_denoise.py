@@ -45,9 +45,8 @@ class TAPModel(Enum):
 
 @dataclass
 class TAPDenoiseConfig:
-    """Field-for-field the reference dataclass (tap_denoise.py:95-131); the default model is NAFNET here because it is
-    the accelerated one (the reference defaults to RESTORMER)."""
-    model: TAPModel = TAPModel.NAFNET
+    """Field-for-field the reference dataclass (tap_denoise.py:95-131), RESTORMER default included (:110)."""
+    model: TAPModel = TAPModel.RESTORMER
     temporal_window: int = 5
     strength: float = 1.0
     preserve_grain: bool = False
@@ -211,7 +210,7 @@ class TAPDenoiser:
 
     # -- availability / model ------------------------------------------------------------------------
     def is_available(self) -> bool:
-        if self.config.model != TAPModel.NAFNET:
+        if self.config.model not in (TAPModel.NAFNET, TAPModel.RESTORMER):
             return False
         try:
             return _lib.load().fw_device_count() > 0
@@ -225,19 +224,25 @@ class TAPDenoiser:
     def _load_model(self) -> None:
         if self._engine is not None:
             return
-        if self.config.model != TAPModel.NAFNET:
-            raise NotImplementedError(f"{self.config.model.value} is not on the accelerated path (only NAFNet is)")
-        eng = NAFNetEngine(dtype=self.config.dtype, device_id=self.config.gpu_id, **NAFNET_ARGS)
+        if self.config.model not in (TAPModel.NAFNET, TAPModel.RESTORMER):
+            raise NotImplementedError(f"{self.config.model.value} is not on the accelerated path (NAFNet and Restormer are)")
+        restormer = self.config.model == TAPModel.RESTORMER
+        if restormer:
+            from .restormer import RESTORMER_ARGS, RestormerEngine, synthetic_restormer_state
+            eng = RestormerEngine(dtype=self.config.dtype, device_id=self.config.gpu_id, **RESTORMER_ARGS)
+        else:
+            eng = NAFNetEngine(dtype=self.config.dtype, device_id=self.config.gpu_id, **NAFNET_ARGS)
         path = self._get_model_path()
         if path is not None:
             import torch
             eng.load_state_dict(torch.load(str(path), map_location="cpu", weights_only=True))
         elif os.environ.get("FRAMEWRIGHT_AMD_SYNTHETIC_WEIGHTS") == "1":
-            logger.warning("using seeded synthetic NAFNet weights (no checkpoint under %s)", self.model_dir)
-            eng.load_state_dict(synthetic_nafnet_state(**NAFNET_ARGS))
+            logger.warning("using seeded synthetic %s weights (no checkpoint under %s)", self.config.model.value, self.model_dir)
+            eng.load_state_dict(synthetic_restormer_state(**RESTORMER_ARGS) if restormer else synthetic_nafnet_state(**NAFNET_ARGS))
         else:
             eng.close()
-            raise FileNotFoundError(f"NAFNet weights not found: {self.model_dir / self.MODEL_FILES[self.config.model]}")
+            raise FileNotFoundError(f"{self.config.model.value} weights not found: "
+                                    f"{self.model_dir / self.MODEL_FILES[self.config.model]}")
         self._engine = eng
 
     # -- device helpers --------------------------------------------------------------------------------
@@ -276,7 +281,8 @@ class TAPDenoiser:
             stw.wait_event(start if wk["free"] is None else wk["free"])
             sp = C.c_void_p(stw.cuda_stream)
             _lib.check(lib.fw_u8_crop(p(frame), h, w, y1, x1, ts, ts, p(wk["tile"]), sp))
-            wk["engine"].denoise_device(wk["tile"], out=wk["out"], stream=stw.cuda_stream)
+            with torch.cuda.stream(stw):   # the engines queue on torch's current stream (and allocate their scratch on it)
+                wk["engine"].denoise_device(wk["tile"], out=wk["out"])
             done[i] = torch.cuda.Event()
             done[i].record(stw)
             # consume in order as soon as this worker's slot is needed again (or at the end)
