@@ -251,6 +251,10 @@ int fw_attn_matrix(int dtype, const void* qkv, long stride, long pixels, int k_o
                    const float* temperature, float* workspace, float* attn, void* stream);
 int fw_attn_apply(int dtype, const void* qkv, long stride, long pixels, int v_off, int heads, int ch, const float* attn,
                   void* out, long out_stride, int zero_to, void* stream);
+/* The attention matrices as one block-diagonal [k_pad x k_pad] weight in fw_pack_pointwise's fragment order (device buffer of
+ * fw_pack_pointwise(dtype, NULL, k_pad, k_pad, NULL) uint16), so that attn @ v runs through fw_pointwise_nhwc on the matrix
+ * cores — what the engine uses; fw_attn_apply is the plain form of the same product. */
+int fw_attn_pack(int dtype, const float* attn, int heads, int ch, int k_pad, void* packed, void* stream);
 
 /* torch.nn.PixelShuffle(2) (unshuffle = 0) / PixelUnshuffle(2) (unshuffle = 1) on fp32 NHWC; low_h x low_w is the
  * low-resolution size, `channels` the channel count at HIGH resolution; dst channels start at dst_coff. */

@@ -91,6 +91,16 @@ def test_attention_matrix_and_apply(hip_lib, dtype, heads, ch, M):
     tol = 3e-3 if dtype == "f16" else 2e-2
     assert (got[:, :dim] - want).abs().max() < tol * max(1.0, want.abs().max().item())
     assert (got[:, dim:] == 0).all()
+    # the same product through the MFMA GEMM with the block-diagonal packed matrix (what the engine runs)
+    apk = torch.empty(int(hip_lib.fw_pack_pointwise(dt, None, cp, cp, None)), dtype=torch.int16, device="cuda")
+    _lib.check(hip_lib.fw_attn_pack(dt, P(attn), heads, ch, cp, P(apk), _st()))
+    out2 = torch.full((M, cp), 7.0, dtype=TDT[dtype], device="cuda")
+    _lib.check(hip_lib.fw_pointwise_nhwc(dt, C.c_void_p(qd.data_ptr() + 2 * cp * 2), 0, 3 * cp, M, cp, P(apk), None, cp // 32,
+                                         P(out2), cp, None, 0, None, None, _st()))
+    torch.cuda.synchronize()
+    got2 = out2.float().cpu()
+    assert (got2[:, :dim] - want).abs().max() < 3 * tol * max(1.0, want.abs().max().item())   # attn rounded to the operand type
+    assert (got2[:, dim:] == 0).all()
 
 
 def test_pixel_shuffle_and_unshuffle(hip_lib):

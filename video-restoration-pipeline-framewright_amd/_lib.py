@@ -32,7 +32,7 @@ EXPORTS = [
     "fw_depth_to_space4_f32", "fw_ifnet_accumulate", "fw_ifnet_blend",
     "fw_u8_to_nhwc", "fw_pixel_shuffle_add_u8",
     "fw_layernorm_nhwc", "fw_pack_pointwise", "fw_pointwise_nhwc", "fw_dwconv3x3_nhwc", "fw_attn_workspace_floats",
-    "fw_attn_matrix", "fw_attn_apply", "fw_pixel_shuffle2_f32", "fw_copy_channels_f32", "fw_f32_to_planar", "fw_tap_post_u8",
+    "fw_attn_matrix", "fw_attn_apply", "fw_attn_pack", "fw_pixel_shuffle2_f32", "fw_copy_channels_f32", "fw_f32_to_planar", "fw_tap_post_u8",
 ]
 
 
@@ -151,6 +151,8 @@ def _declare_ifnet(lib: C.CDLL) -> None:
     lib.fw_attn_matrix.argtypes = [i32, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp]
     lib.fw_attn_apply.restype = i32
     lib.fw_attn_apply.argtypes = [i32, vp, i64, i64, i32, i32, i32, vp, vp, i64, i32, vp]
+    lib.fw_attn_pack.restype = i32
+    lib.fw_attn_pack.argtypes = [i32, vp, i32, i32, i32, vp, vp]
     lib.fw_pixel_shuffle2_f32.restype = i32
     lib.fw_pixel_shuffle2_f32.argtypes = [vp, i64, i32, i32, i32, vp, i64, i32, i32, vp]
     lib.fw_copy_channels_f32.restype = i32

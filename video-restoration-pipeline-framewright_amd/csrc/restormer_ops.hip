@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_nhwc_kernel(const T* __restrict
 //   [h][c1][c2] = sum_p q[p][h*ch+c1] * k[p][h*ch+c2] over the block's pixels, then sum q^2 and sum k^2 per channel.
 // A thread owns 3x3 patches of (c1, c2): patch index -> (head, c1/3, c2/3); pixels are staged 16 at a time through LDS.
 constexpr int GRAM_PX = 16;
-constexpr int GRAM_MAX_BLOCKS = 512;
+constexpr int GRAM_MAX_BLOCKS = 128;
 template <typename T>
 __global__ __launch_bounds__(256) void attn_gram_kernel(const T* __restrict__ qkv, long ld, long M, int k_off, int heads, int ch,
                                                         float* partial) {
@@ -213,6 +213,7 @@ __global__ __launch_bounds__(128) void attn_finish_kernel(const float* __restric
     const size_t stride = (size_t)dim * ch + 2 * dim;
     float g = 0.f, kn = 0.f, qn = 0.f;
     if (c2 < ch) {
+#pragma unroll 8
         for (int b = 0; b < nblocks; ++b) {
             const float* pb = partial + b * stride;
             g += pb[(h * ch + c1) * ch + c2];
@@ -239,6 +240,27 @@ __global__ __launch_bounds__(128) void attn_finish_kernel(const float* __restric
         __syncthreads();
     }
     if (c2 < ch) attn[((size_t)h * ch + c1) * ch + c2] = e / red[0];
+}
+
+// The attention matrices as ONE block-diagonal [kp x kp] weight in the fragment order of pack_pointwise_weights
+// ([chunk][ks][cout tile][lane][8]: cout = 32*tile + (lane & 31), k = 32*chunk + 16*ks + 8*(lane >> 5) + j), operand-typed,
+// so that "attn @ v" runs as a 1x1 convolution on the pointwise MFMA GEMM (the zeros of the other heads cost nothing that
+// matters next to a VALU mat-vec per pixel).
+template <typename T>
+__global__ __launch_bounds__(256) void attn_pack_kernel(const float* __restrict__ attn, int heads, int ch, int kp, T* dst) {
+    const int dim = heads * ch, nt = kp / 32;
+    const long total = (long)nt * 2 * nt * 64 * 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        long r = i >> 9;
+        const int t = (int)(r % nt);
+        r /= nt;
+        const int ks = (int)(r & 1), c = (int)(r >> 1);
+        const int co = 32 * t + (lane & 31), k = 32 * c + 16 * ks + 8 * (lane >> 5) + j;
+        float v = 0.f;
+        if (co < dim && k < dim && co / ch == k / ch) v = attn[((size_t)(co / ch) * ch + co % ch) * ch + k % ch];
+        dst[i] = (T)v;
+    }
 }
 
 // out[p][h*ch + c1] = sum_c2 A[h][c1][c2] * v[p][v_off + h*ch + c2]; typed out, channels [dim, Cz) zeroed.
@@ -436,6 +458,20 @@ int fw_attn_matrix(int dtype, const void* qkv, long ld, long M, int k_off, int h
         else
             hipLaunchKernelGGL((attn_gram_kernel<_Float16>), dim3(nb), dim3(256), smem, st, (const _Float16*)qkv, ld, M, k_off, heads, ch, workspace);
         hipLaunchKernelGGL(attn_finish_kernel, dim3(heads * ch), dim3(128), 0, st, (const float*)workspace, nb, heads, ch, temperature, attn);
+        FW_HIP_CHECK(hipGetLastError());
+    });
+}
+
+int fw_attn_pack(int dtype, const float* attn, int heads, int ch, int k_pad, void* packed, void* stream) {
+    if (bad_dtype(dtype) || !attn || !packed || heads < 1 || ch < 8 || k_pad < heads * ch || (k_pad & 31))
+        return rfail(FW_ERR_INVALID, "fw_attn_pack: bad argument");
+    return rguard([&] {
+        const long total = (long)(k_pad / 32) * 2 * (k_pad / 32) * 64 * 8;
+        const int blocks = blocks_for(total, 1024);
+        if (dtype == FW_DTYPE_BF16)
+            hipLaunchKernelGGL((attn_pack_kernel<__bf16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, attn, heads, ch, k_pad, (__bf16*)packed);
+        else
+            hipLaunchKernelGGL((attn_pack_kernel<_Float16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, attn, heads, ch, k_pad, (_Float16*)packed);
         FW_HIP_CHECK(hipGetLastError());
     });
 }

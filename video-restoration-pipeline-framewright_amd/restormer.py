@@ -237,7 +237,11 @@ class RestormerEngine:
             ws = f32(lib.fw_attn_workspace_floats(heads, ch))
             attn = f32(heads, ch, ch)
             _lib.check(lib.fw_attn_matrix(dt, p(qkv2), 3 * cp, M, cp, heads, ch, p(blk["temp"]), p(ws), p(attn), st))
-            _lib.check(lib.fw_attn_apply(dt, p(qkv2), 3 * cp, M, 2 * cp, heads, ch, p(attn), p(t), cp, cp, st))
+            # attn @ v as a 1x1 convolution with the block-diagonal attention matrix on the MFMA GEMM
+            apk = torch.empty(int(lib.fw_pack_pointwise(dt, None, cp, cp, None)), dtype=torch.int16, device=dev)
+            _lib.check(lib.fw_attn_pack(dt, p(attn), heads, ch, cp, p(apk), st))
+            _lib.check(lib.fw_pointwise_nhwc(dt, C.c_void_p(qkv2.data_ptr() + 2 * cp * 2), 0, 3 * cp, M, cp, p(apk), None, cp // 32,
+                                             p(t), cp, None, 0, None, None, st))
             _lib.check(lib.fw_pointwise_nhwc(dt, p(t), 0, cp, M, cp, p(blk["proj"]), None, blk["proj_t"], None, 0, p(x), cp, p(x),
                                              p(W["ones"]), st))
             _lib.check(lib.fw_layernorm_nhwc(dt, p(x), cp, M, c, p(blk["n2w"]), p(blk["n2b"]), 1e-5, p(t), cp, cp, st))
