@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_nhwc_kernel(const T* __restrict
 //   [h][c1][c2] = sum_p q[p][h*ch+c1] * k[p][h*ch+c2] over the block's pixels, then sum q^2 and sum k^2 per channel.
 // A thread owns 3x3 patches of (c1, c2): patch index -> (head, c1/3, c2/3); pixels are staged 16 at a time through LDS.
 constexpr int GRAM_PX = 16;
-constexpr int GRAM_MAX_BLOCKS = 128;
+constexpr int GRAM_MAX_BLOCKS = 512;
 template <typename T>
 __global__ __launch_bounds__(256) void attn_gram_kernel(const T* __restrict__ qkv, long ld, long M, int k_off, int heads, int ch,
                                                         float* partial) {
@@ -201,25 +201,30 @@ __global__ __launch_bounds__(256) void attn_gram_kernel(const T* __restrict__ qk
     }
 }
 
-// Sum the partials in block order (deterministic), then A[h][c1][:] = softmax_c2(G / (|q_c1| |k_c2|) * temperature[h])
-// with F.normalize's clamp (norm >= 1e-12).  One workgroup per (head, c1) row.
-__global__ __launch_bounds__(128) void attn_finish_kernel(const float* __restrict__ partial, int nblocks, int heads, int ch,
+// Sum the partials in block order (one thread per element, coalesced across elements; a fixed order -> deterministic) into
+// the first row of the workspace.
+__global__ __launch_bounds__(256) void attn_reduce_kernel(float* partial, int nblocks, long stride) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= stride) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * stride + e];
+    partial[e] = s;   // row 0 is read by its own thread only: in place
+}
+
+// A[h][c1][:] = softmax_c2(G / (|q_c1| |k_c2|) * temperature[h]) with F.normalize's clamp (norm >= 1e-12), from the reduced
+// sums.  One workgroup per (head, c1) row.
+__global__ __launch_bounds__(128) void attn_finish_kernel(const float* __restrict__ sums, int heads, int ch,
                                                           const float* __restrict__ temperature, float* attn) {
     __shared__ float row[128];
     __shared__ float red[128];
     const int dim = heads * ch;
     const int h = blockIdx.x / ch, c1 = blockIdx.x - h * ch;
     const int c2 = threadIdx.x;
-    const size_t stride = (size_t)dim * ch + 2 * dim;
-    float g = 0.f, kn = 0.f, qn = 0.f;
     if (c2 < ch) {
-#pragma unroll 8
-        for (int b = 0; b < nblocks; ++b) {
-            const float* pb = partial + b * stride;
-            g += pb[(h * ch + c1) * ch + c2];
-            kn += pb[dim * ch + dim + h * ch + c2];
-            qn += pb[dim * ch + h * ch + c1];
-        }
+        const float g = sums[(h * ch + c1) * ch + c2];
+        const float kn = sums[dim * ch + dim + h * ch + c2];
+        const float qn = sums[dim * ch + h * ch + c1];
         const float dq = fmaxf(sqrtf(qn), 1e-12f), dk = fmaxf(sqrtf(kn), 1e-12f);
         row[c2] = g / (dq * dk) * temperature[h];
     }
@@ -457,7 +462,9 @@ int fw_attn_matrix(int dtype, const void* qkv, long ld, long M, int k_off, int h
             hipLaunchKernelGGL((attn_gram_kernel<__bf16>), dim3(nb), dim3(256), smem, st, (const __bf16*)qkv, ld, M, k_off, heads, ch, workspace);
         else
             hipLaunchKernelGGL((attn_gram_kernel<_Float16>), dim3(nb), dim3(256), smem, st, (const _Float16*)qkv, ld, M, k_off, heads, ch, workspace);
-        hipLaunchKernelGGL(attn_finish_kernel, dim3(heads * ch), dim3(128), 0, st, (const float*)workspace, nb, heads, ch, temperature, attn);
+        const long stride = (long)dim * ch + 2 * dim;
+        hipLaunchKernelGGL(attn_reduce_kernel, dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, st, workspace, nb, stride);
+        hipLaunchKernelGGL(attn_finish_kernel, dim3(heads * ch), dim3(128), 0, st, (const float*)workspace, heads, ch, temperature, attn);
         FW_HIP_CHECK(hipGetLastError());
     });
 }
