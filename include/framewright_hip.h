@@ -271,6 +271,24 @@ int fw_tap_post_u8(const uint8_t* in_bgr, const float* rgb, int height, int widt
                    uint8_t* out_bgr, float* out_rgb_f32, void* stream);
 
 /* -------------------------------------------------------------------------------------------------
+ * Classical motion-compensated temporal denoise (device pointers)
+ * replaces  OpticalFlowEstimator.warp_frame (processors/temporal_denoise.py:440-477) and the accumulation of
+ *           TemporalDenoiser._denoise_with_flow / _denoise_simple (:1521-1605).  The dense flow (cv2 Farneback / DIS) is
+ *           estimated on the host and is not part of this path.
+ * ------------------------------------------------------------------------------------------------- */
+
+/* accumulated[p] += aligned[p] * w[p]; weight_sum[p] += w[p]  (float64, like the reference), with
+ *   aligned = flow ? cv2.remap(frame, x +/- flow_x, y +/- flow_y, INTER_LINEAR, BORDER_REFLECT_101) : frame
+ *   w       = weight_scale * (weight_map ? weight_map[p] : 1), halved where magnitude[p] > motion_threshold.
+ * flow_x / flow_y / weight_map / magnitude: fp32 [H][W] or NULL; inverse != 0 subtracts the flow. */
+int fw_flow_accumulate_u8(const uint8_t* frame_bgr, const float* flow_x, const float* flow_y, const float* weight_map,
+                          double weight_scale, const float* magnitude, float motion_threshold, int inverse, int height,
+                          int width, double* accumulated, double* weight_sum, void* stream);
+/* out = (accumulated / max(weight_sum, 1e-6)).astype(uint8) */
+int fw_flow_accumulate_finish_u8(const double* accumulated, const double* weight_sum, int height, int width,
+                                 uint8_t* out_bgr, void* stream);
+
+/* -------------------------------------------------------------------------------------------------
  * RIFE frame interpolation: IFNet v4.6 building blocks (device pointers, fp32 NHWC small-channel tensors)
  * replaces  the arithmetic inside the external binary the reference shells out to,
  *           `rife-ncnn-vulkan -m rife-v4.6` (processors/interpolation.py:628-650); architecture per SURVEY.md §A.5.

@@ -1,0 +1,60 @@
+"""Classical motion-compensated temporal denoise kernels against oracle/temporal_ref.py (bit-exact: integer remap
+arithmetic, float64 accumulation in the reference's order)."""
+import numpy as np
+import pytest
+
+from framewright_amd import temporal_denoise as TD
+from framewright_amd.synth import synthetic_frames
+from oracle import temporal_ref as ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _flow(rng, h, w, amp):
+    fx = (rng.standard_normal((h, w)) * amp).astype(np.float32)
+    fy = (rng.standard_normal((h, w)) * amp).astype(np.float32)
+    mag = np.sqrt(fx ** 2 + fy ** 2)
+    conf = rng.random((h, w)).astype(np.float32)
+    return TD.FlowField(fx, fy, mag, conf)
+
+
+@pytest.mark.parametrize("h,w,amp,inverse", [(37, 53, 1.5, False), (16, 16, 6.0, True), (5, 3, 12.0, False), (1, 9, 2.0, False)])
+def test_warp_frame_bit_exact(hip_lib, h, w, amp, inverse):
+    rng = np.random.default_rng(h * 100 + w)
+    frame = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    fl = _flow(rng, h, w, amp)
+    fl.flow_x[0, 0] = 0.0          # an exact grid point
+    fl.flow_y[0, 0] = 0.0
+    acc = TD.DeviceTemporalAccumulator()
+    got = acc.warp_frame(frame, fl, inverse=inverse)
+    np.testing.assert_array_equal(got, ref.warp_frame(frame, fl.flow_x, fl.flow_y, inverse=inverse))
+    assert tuple(got[0, 0]) == tuple(frame[0, 0])
+
+
+@pytest.mark.parametrize("n,center,decay", [(7, 3, 0.5), (4, 0, 0.2), (3, 2, 1.0)])
+def test_denoise_with_flow_bit_exact(hip_lib, n, center, decay):
+    rng = np.random.default_rng(n * 10 + center)
+    frames = list(synthetic_frames(n, 41, 59, seed=n))
+    flows = [None if i == center else _flow(rng, 41, 59, 2.0) for i in range(n)]
+    failing = 1 if center != 1 else 0                 # flow estimation "fails" for one neighbour: unaligned fallback
+    by_id = {id(f): fl for f, fl in zip(frames, flows)}
+
+    def flow_fn(frame, center_frame):
+        if frame is frames[failing]:
+            raise RuntimeError("flow failed")
+        return by_id[id(frame)]
+
+    acc = TD.DeviceTemporalAccumulator(temporal_weight_decay=decay, flow_fn=flow_fn)
+    got = acc.denoise_with_flow(center, frames)
+    oflows = [None if (fl is None or i == failing) else dict(flow_x=fl.flow_x, flow_y=fl.flow_y, magnitude=fl.magnitude,
+                                                              confidence=fl.confidence) for i, fl in enumerate(flows)]
+    np.testing.assert_array_equal(got, ref.denoise_with_flow(center, frames, oflows, decay))
+
+
+def test_denoise_simple_bit_exact_and_missing_flow_estimator(hip_lib):
+    frames = list(synthetic_frames(5, 30, 44, seed=3))
+    acc = TD.DeviceTemporalAccumulator(temporal_weight_decay=0.5)
+    np.testing.assert_array_equal(acc.denoise_simple(frames), ref.denoise_simple(frames, 0.5))
+    # no estimator: every neighbour falls back to the unaligned frame with the temporal weight only, as in the reference
+    got = acc.denoise_with_flow(2, frames)
+    np.testing.assert_array_equal(got, ref.denoise_with_flow(2, frames, [None] * 5, 0.5))

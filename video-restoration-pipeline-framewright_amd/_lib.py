@@ -33,6 +33,7 @@ EXPORTS = [
     "fw_u8_to_nhwc", "fw_pixel_shuffle_add_u8",
     "fw_layernorm_nhwc", "fw_pack_pointwise", "fw_pointwise_nhwc", "fw_dwconv3x3_nhwc", "fw_attn_workspace_floats",
     "fw_attn_matrix", "fw_attn_apply", "fw_attn_pack", "fw_pixel_shuffle2_f32", "fw_copy_channels_f32", "fw_f32_to_planar", "fw_tap_post_u8",
+    "fw_flow_accumulate_u8", "fw_flow_accumulate_finish_u8",
 ]
 
 
@@ -159,6 +160,10 @@ def _declare_ifnet(lib: C.CDLL) -> None:
     lib.fw_copy_channels_f32.argtypes = [vp, i64, i64, i32, vp, i64, i32, vp]
     lib.fw_f32_to_planar.restype = i32
     lib.fw_f32_to_planar.argtypes = [i32, vp, i64, i32, vp, vp]
+    lib.fw_flow_accumulate_u8.restype = i32
+    lib.fw_flow_accumulate_u8.argtypes = [vp, vp, vp, vp, C.c_double, vp, f32, i32, i32, i32, vp, vp, vp]
+    lib.fw_flow_accumulate_finish_u8.restype = i32
+    lib.fw_flow_accumulate_finish_u8.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.fw_tap_post_u8.restype = i32
     lib.fw_tap_post_u8.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
 

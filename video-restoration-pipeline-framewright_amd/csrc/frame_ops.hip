@@ -94,6 +94,79 @@ void launch_u8_to_nhwc(DType dt, const uint8_t* in_bgr, int H, int W, void* out,
 }
 
 
+// ---- classical motion-compensated temporal denoise (reference src/framewright/processors/temporal_denoise.py:440-477
+//      `warp_frame` and :1521-1580 `_denoise_with_flow`): per neighbour frame  aligned = cv2.remap(frame, x + flow_x,
+//      y + flow_y, INTER_LINEAR, BORDER_REFLECT_101);  weight = exp(-d*decay) * confidence, halved where the flow magnitude
+//      exceeds its 90th percentile;  accumulated += aligned (float64) * weight;  weight_sum += weight;  result =
+//      (accumulated / max(weight_sum, 1e-6)).astype(uint8).
+//      The remap restates OpenCV's 8-bit INTER_LINEAR arithmetic (coordinates rounded to 1/32 pixel with round-half-even,
+//      15-bit coefficients, (sum + 2^14) >> 15); cv2 is absent from the build container, so that restatement is unpinned.
+//      The dense flow itself (cv2 Farneback / DIS) stays on the host: it is not part of this path. --------------------------
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * len - p - 2;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void flow_accumulate_kernel(const uint8_t* __restrict__ frame, const float* __restrict__ fx,
+                                                              const float* __restrict__ fy, const float* __restrict__ wmap,
+                                                              double wscale, const float* __restrict__ mag, float thr,
+                                                              int inverse, int H, int W, double* acc, double* wsum) {
+    const long n = (long)H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W), x = (int)(i - (long)y * W);
+        double v[3];
+        if (fx) {
+            // map = (grid +/- flow).astype(float32); cv2.remap fixed-point: round(map * 32), 5 fractional bits
+            const float mx = inverse ? (float)((double)x - (double)fx[i]) : (float)((double)x + (double)fx[i]);
+            const float my = inverse ? (float)((double)y - (double)fy[i]) : (float)((double)y + (double)fy[i]);
+            const int sx = (int)rintf(mx * 32.0f), sy = (int)rintf(my * 32.0f);
+            const int ix = sx >> 5, iy = sy >> 5, ax = sx & 31, ay = sy & 31;
+            const int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
+            const int x0 = reflect101(ix, W), x1 = reflect101(ix + 1, W), y0 = reflect101(iy, H), y1 = reflect101(iy + 1, H);
+            const uint8_t* p00 = frame + ((size_t)y0 * W + x0) * 3;
+            const uint8_t* p01 = frame + ((size_t)y0 * W + x1) * 3;
+            const uint8_t* p10 = frame + ((size_t)y1 * W + x0) * 3;
+            const uint8_t* p11 = frame + ((size_t)y1 * W + x1) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                v[c] = (double)((p00[c] * w00 + p01[c] * w01 + p10[c] * w10 + p11[c] * w11 + (1 << 14)) >> 15);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = (double)frame[(size_t)i * 3 + c];
+        }
+        double w = wmap ? wscale * (double)wmap[i] : wscale;
+        if (mag && mag[i] > thr) w *= 0.5;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[(size_t)i * 3 + c] += v[c] * w;
+        wsum[i] += w;
+    }
+}
+
+__global__ __launch_bounds__(256) void flow_accumulate_finish_kernel(const double* __restrict__ acc, const double* __restrict__ wsum,
+                                                                     long n, uint8_t* out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const double d = fmax(wsum[i], 1e-6);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[(size_t)i * 3 + c] = (uint8_t)(acc[(size_t)i * 3 + c] / d);
+    }
+}
+
+void launch_flow_accumulate(const uint8_t* frame, const float* fx, const float* fy, const float* wmap, double wscale,
+                            const float* mag, float thr, int inverse, int H, int W, double* acc, double* wsum, hipStream_t st) {
+    const long n = (long)H * W;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(flow_accumulate_kernel, dim3(blocks), dim3(256), 0, st, frame, fx, fy, wmap, wscale, mag, thr, inverse, H, W,
+                       acc, wsum);
+    FW_HIP_CHECK(hipGetLastError());
+}
+
+void launch_flow_accumulate_finish(const double* acc, const double* wsum, long n, uint8_t* out, hipStream_t st) {
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(flow_accumulate_finish_kernel, dim3(blocks), dim3(256), 0, st, acc, wsum, n, out);
+    FW_HIP_CHECK(hipGetLastError());
+}
+
 // ---- SRVGGNetCompact tail (Real-ESRGAN realesr-animevideov3 / realesr-general-x4v3; reference model table
 //      src/framewright/processors/pytorch_realesrgan.py:119-128 declares them, the network itself is third-party) ---------
 __global__ __launch_bounds__(256) void pixel_shuffle_add_kernel(const float* __restrict__ conv, int cstride,

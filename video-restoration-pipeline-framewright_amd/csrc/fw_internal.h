@@ -165,6 +165,10 @@ void launch_temporal_average(const uint8_t* const* frames, const float* weights,
 void launch_strength_blend(const uint8_t* orig, const uint8_t* den, float one_minus_s, float s, long n, uint8_t* out,
                            hipStream_t st);
 
+void launch_flow_accumulate(const uint8_t* frame, const float* fx, const float* fy, const float* wmap, double wscale,
+                            const float* mag, float thr, int inverse, int H, int W, double* acc, double* wsum, hipStream_t st);
+void launch_flow_accumulate_finish(const double* acc, const double* wsum, long n, uint8_t* out, hipStream_t st);
+
 // thread-local message returned by fw_last_error()
 std::string& last_error_ref();
 

@@ -540,4 +540,21 @@ int fw_tap_post_u8(const uint8_t* in_bgr, const float* rgb, int H, int W, int pa
     return rguard([&] { launch_tap_post(in_bgr, rgb, H, W, padded_w, rgb_cstride, out_bgr, out_rgb_f32, (hipStream_t)stream); });
 }
 
+int fw_flow_accumulate_u8(const uint8_t* frame_bgr, const float* flow_x, const float* flow_y, const float* weight_map,
+                          double weight_scale, const float* magnitude, float motion_threshold, int inverse, int H, int W,
+                          double* accumulated, double* weight_sum, void* stream) {
+    if (!frame_bgr || !accumulated || !weight_sum || H < 1 || W < 1 || (!flow_x != !flow_y))
+        return rfail(FW_ERR_INVALID, "fw_flow_accumulate_u8: bad argument");
+    return rguard([&] {
+        launch_flow_accumulate(frame_bgr, flow_x, flow_y, weight_map, weight_scale, magnitude, motion_threshold, inverse, H, W,
+                               accumulated, weight_sum, (hipStream_t)stream);
+    });
+}
+
+int fw_flow_accumulate_finish_u8(const double* accumulated, const double* weight_sum, int H, int W, uint8_t* out_bgr,
+                                 void* stream) {
+    if (!accumulated || !weight_sum || !out_bgr || H < 1 || W < 1) return rfail(FW_ERR_INVALID, "fw_flow_accumulate_finish_u8: bad argument");
+    return rguard([&] { launch_flow_accumulate_finish(accumulated, weight_sum, (long)H * W, out_bgr, (hipStream_t)stream); });
+}
+
 }  // extern "C"
