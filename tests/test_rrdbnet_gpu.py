@@ -162,6 +162,28 @@ def test_split_trunk_matches_fp32_trunk(hip_lib, monkeypatch, dtype, tol_max, to
     assert e_s < 1.25 * e_f + 1e-6, (e_s, e_f)
 
 
+@pytest.mark.parametrize("H,W", [(1, 1), (2, 3), (7, 5), (14, 30), (15, 31), (16, 32), (17, 33), (29, 61), (100, 100), (333, 517)])
+def test_fused_split_path_equals_plain_path_on_ragged_sizes(hip_lib, monkeypatch, H, W):
+    """The default build (fused conv pairs on 14x30 tiles, split trunk, DMA batches with the border-tile fallback) against
+    the plain one-conv-per-launch fp32-trunk path over sizes that put every kind of border tile in play: below one tile,
+    exactly one pair tile, one pixel more than a tile in each direction, many tiles.  The two paths round at the same
+    points except for the trunk representation, so they agree to rounding-flip noise; an addressing bug would not."""
+    sd = synthetic_rrdbnet_state(2, 4, seed=H * 1000 + W)
+    frame = synthetic_frames(1, H, W, seed=W)[0]
+    outs = []
+    for fuse, split in (("1", "1"), ("0", "0")):
+        monkeypatch.setenv("FW_RRDB_FUSE_PAIRS", fuse)
+        monkeypatch.setenv("FW_RRDB_SPLIT_TRUNK", split)
+        eng = R.RRDBNetEngine(2, 4, "f16")
+        eng.load_state_dict(sd)
+        outs.append(_gpu_rgb_f32(eng, frame))
+        eng.close()
+    (rgb_a, u8_a), (rgb_b, u8_b) = outs
+    assert np.isfinite(rgb_a).all()
+    assert np.abs(rgb_a - rgb_b).max() < 2e-4
+    assert np.abs(u8_a.astype(int) - u8_b.astype(int)).max() <= 1
+
+
 def test_upscale_host_buffers_and_determinism(hip_lib):
     sd = synthetic_rrdbnet_state(2, 4, seed=5)
     frame = synthetic_frames(1, 30, 50, seed=3)[0]

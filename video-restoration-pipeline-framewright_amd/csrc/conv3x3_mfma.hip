@@ -515,7 +515,8 @@ void launch_conv3x3(DType dt, int cout_tiles, ConvEpilogue epi, const ConvParams
     if (p.H <= 0 || p.W <= 0 || p.cin_chunks <= 0) throw Error(1, "conv3x3: empty problem");
     if (p.upsample2x && ((p.H | p.W) & 1)) throw Error(1, "conv3x3: upsample2x needs even output size");
     if (p.in_cstride < 32 || (p.in_cstride & 7) || p.in_pstride < 32 || (p.in_pstride & 7) ||
-        (p.in_pstride == 32 && p.in_cstride < 32 * p.cin_chunks))
+        (p.in_pstride == 32 && p.in_cstride < 32 * p.cin_chunks &&
+         (long)(p.upsample2x ? p.H / 2 : p.H) * (p.upsample2x ? p.W / 2 : p.W) > 1))  // (a 1-pixel planar input IS interleaved)
         throw Error(1, "conv3x3: bad input channel/plane stride");
     if (p.out && cout_tiles == 2 && (p.out_pstride < 32 || (p.out_pstride & 7)))
         throw Error(1, "conv3x3: bad output plane stride");

@@ -273,18 +273,22 @@ __device__ __forceinline__ void conv_item(f32x4 (&acc)[RPW][NW][2], const uint4*
     constexpr int NWU = NW - W_LO;
     constexpr int NK = 9 * NWU;  // weight fragments of the item, in use order
     uint4 xr[RPW + 2][2];
-    uint4 wf[3];
+#ifndef FW_WRING
+#define FW_WRING 3
+#endif
+    constexpr int RING = FW_WRING;   // weight-fragment register ring: fragments are read RING - 1 tiles ahead
+    uint4 wf[RING];
     auto load_w = [&](int k) {
         const int t = k / NWU, w = k - t * NWU;
         const int dx = t / 3, dy = t - 3 * dx;
-        wf[k % 3] = wl[widx(dy * 3 + dx, W_LO + w) * 64];
+        wf[k % RING] = wl[widx(dy * 3 + dx, W_LO + w) * 64];
     };
 #pragma unroll
     for (int row = 0; row < RPW + 2; ++row)
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) xr[row][ph] = a[row * ROW_PIECES + rd_off[0][ph]];
-    load_w(0);
-    load_w(1);
+#pragma unroll
+    for (int k = 0; k < RING - 1; ++k) load_w(k);
     FW_SB();
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -302,13 +306,13 @@ __device__ __forceinline__ void conv_item(f32x4 (&acc)[RPW][NW][2], const uint4*
 #pragma unroll
         for (int w = 0; w < NWU; ++w) {
             const int k = t * NWU + w;
-            if (k + 2 < NK) load_w(k + 2);
+            if (k + RING - 1 < NK) load_w(k + RING - 1);
             FW_SB();
 #pragma unroll
             for (int row = 0; row < RPW; ++row)
 #pragma unroll
                 for (int ph = 0; ph < 2; ++ph)
-                    acc[row][W_LO + w][ph] = Op<T>::mfma16(wf[k % 3], xr[row + dy][ph], acc[row][W_LO + w][ph]);
+                    acc[row][W_LO + w][ph] = Op<T>::mfma16(wf[k % RING], xr[row + dy][ph], acc[row][W_LO + w][ph]);
             FW_SB();
             // 36 slots per item: NWU = 4 -> one per weight tile; NWU = 2 -> two per weight tile
 #pragma unroll
