@@ -41,9 +41,6 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
     const int sl = lane >> 4;  // 8-channel slot of the 32-channel chunk (A/B k index), 4-channel group of the D tile
     constexpr bool SPLIT = EPI == EPI_RESIDUAL_SPLIT;
     FW_STAMP_INIT();
-#ifdef FW_SETPRIO
-    if (wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(FW_SETPRIO);
-#endif
 
     // ---- persistent workgroup: a contiguous range of tiles ---------------------------------------------------
     // Blocks b and b+8 share an XCD (and its L2): logical id lb puts the blocks of one XCD on a contiguous band of
@@ -276,15 +273,7 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
                         if (c < CT && p.in_id_scale != 0.f) add_identity(xc, p.in_id_scale, c);
                     }
                 },
-                [&](int step) {
-#ifdef FW_PRIO_ALT
-                    if (wave >= NWAVES / 2) {
-                        if (step & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-                    } else {
-                        if (step & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
-                    }
-#endif
-                });
+                [](int) {});
             FW_STAMP(1);  // item compute
             if constexpr (SPLIT) {
                 if (has_id) add_identity(idx, p.id_scale[c], c & 1);

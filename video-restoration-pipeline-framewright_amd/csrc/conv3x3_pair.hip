@@ -47,9 +47,6 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_kern
     const int q = lane & 15;   // pixel within a 16-pixel half row (B/D column), output channel within a tile (A row)
     const int sl = lane >> 4;  // 8-channel slot of the chunk (A/B k index), 4-channel group of the D tile
     FW_STAMP_INIT();
-#ifdef FW_SETPRIO
-    if (wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(FW_SETPRIO);
-#endif
 
     const int NB = gridDim.x;
     const int xcd = blockIdx.x & 7;
@@ -263,13 +260,6 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_kern
             const uint4* wl = lds + SM::W_BASE + (n & 1) * SM::W_REGION + lane;
             auto& slot_fn = dma_slot;
             conv_item<T, NW, BOTH ? 0 : 2>(acc, a, wl, rd_off, widx, slot_fn, [](const uint4 (&)[RPW][2]) {}, [&](int step) {
-#ifdef FW_PRIO_ALT  // experiment: the two waves of a SIMD take turns at priority 1, one step each
-                if (wave >= NWAVES / 2) {
-                    if (step & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-                } else {
-                    if (step & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
-                }
-#endif
 #ifdef FW_STEP_STAMPS  // BOTH items: slot 1 = steps 0-2 (the DMA slots), 6 = steps 3-5, 4 = steps 6-8
                 if (BOTH && step == 2) FW_STAMP(1);
                 if (BOTH && step == 5) FW_STAMP(6);
@@ -286,11 +276,7 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_kern
         __syncthreads();
         FW_STAMP(0);
         // the whole 16x32 compute region inside the image?  (uniform; false only for border tiles)
-#ifdef FW_EMIT_NO_FASTPATH  // A/B switch
-        const bool interior = false;
-#else
         const bool interior = oy >= 0 && ox >= 0 && oy + TILE_H <= p.H && ox + TILE_W <= p.W;
-#endif
         if (!(FW_PAIR_DBG & 4)) {
             if (interior)
                 emit(0, lds + ((qd - 1) & 1) * ACT_REGION, oy, ox, reinterpret_cast<T*>(p.out_a), true, std::true_type{});
