@@ -78,7 +78,9 @@ def main():
     torch.cuda.set_device(dev_ord)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if "FW_BENCH_FORCE_DEVICE" in os.environ else "nccl")
+        # one rank per GPU over RCCL; the single-card rehearsal (FW_BENCH_FORCE_DEVICE) uses gloo unless told otherwise
+        backend = os.environ.get("FW_BENCH_BACKEND", "gloo" if "FW_BENCH_FORCE_DEVICE" in os.environ else "nccl")
+        dist.init_process_group(backend)
 
     from framewright_amd import build as fw_build
     if rank == 0:
@@ -125,7 +127,8 @@ def main():
     barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    t = torch.tensor([wall], dtype=torch.float64, device="cpu" if "FW_BENCH_FORCE_DEVICE" in os.environ else "cuda")
+    t = torch.tensor([wall], dtype=torch.float64,
+                     device="cuda" if (world > 1 and dist.get_backend() == "nccl") or world == 1 else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
