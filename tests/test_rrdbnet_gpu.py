@@ -184,6 +184,24 @@ def test_fused_split_path_equals_plain_path_on_ragged_sizes(hip_lib, monkeypatch
     assert np.abs(u8_a.astype(int) - u8_b.astype(int)).max() <= 1
 
 
+def test_upscale_stream_overlapped_copies_equal_frame_by_frame(hip_lib):
+    """The 3-stream host pipeline (upload / compute / download overlapped, pinned staging) returns, in order, exactly what
+    the synchronous per-frame call returns."""
+    sd = synthetic_rrdbnet_state(2, 4, seed=8)
+    eng = R.RRDBNetEngine(2, 4, "bf16")
+    eng.load_state_dict(sd)
+    frames = list(synthetic_frames(7, 33, 47, seed=4))
+    want = [eng.upscale(f) for f in frames]
+    got = [o.copy() for o in eng.upscale_stream(frames, depth=2)]
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    assert list(eng.upscale_stream([])) == []
+    with pytest.raises(ValueError):
+        list(eng.upscale_stream([frames[0], frames[1][:20]]))
+    eng.close()
+
+
 def test_upscale_host_buffers_and_determinism(hip_lib):
     sd = synthetic_rrdbnet_state(2, 4, seed=5)
     frame = synthetic_frames(1, 30, 50, seed=3)[0]

@@ -28,4 +28,9 @@ t0 = time.perf_counter()
 for _ in range(3): eng.upscale_device(d, out=o)
 torch.cuda.synchronize()
 res["hbm_resident_ms_per_frame"] = (time.perf_counter() - t0) / 3 * 1e3
+frames = [f] * 16
+for _ in eng.upscale_stream(frames[:2]): pass
+t0 = time.perf_counter()
+n = sum(1 for _ in eng.upscale_stream(frames))
+res["pipelined_host_ms_per_frame"] = (time.perf_counter() - t0) / n * 1e3
 print(json.dumps(res))

@@ -120,6 +120,68 @@ class RRDBNetEngine:
             C.c_void_p(out_rgb_f32.data_ptr()) if out_rgb_f32 is not None else None, C.c_void_p(stream)))
         return out if out is not None else out_rgb_f32
 
+    def upscale_stream(self, frames, depth: int = 2):
+        """Host frames in, host frames out, with the PCIe copies overlapped with compute: generator over uint8 BGR results
+        in input order.  Three streams (upload / compute / download) and ``depth`` + 1 pinned staging slots each way: frame
+        n+1 uploads and frame n-1 downloads while frame n computes (6.2 MB in, 99.5 MB out per 1080p x4 frame).  The
+        yielded array is a view of a pinned slot that is reused ``depth`` frames later: copy it if it must outlive that."""
+        import torch
+        dev = torch.device("cuda", self.device_id)
+        s = self.scale
+        up, comp, down = (torch.cuda.Stream(device=dev) for _ in range(3))
+        slots = depth + 1
+        pin_in = pin_out = d_in = d_out = None
+        cache = self.__dict__.setdefault("_stream_slots", {})   # pinning 100 MB slots costs tens of ms: keep them
+        pending = []   # (slot, download-done event)
+        ev_in_free = [None] * slots    # compute finished reading d_in[slot]
+        ev_out_free = [None] * slots   # download finished reading d_out[slot]
+
+        def drain(limit):
+            while len(pending) > limit:
+                k, ev = pending.pop(0)
+                ev.synchronize()
+                yield pin_out[k].numpy()
+
+        for n, f in enumerate(frames):
+            f = _check_frame(f)
+            h, w = f.shape[:2]
+            if pin_in is None:
+                key = (h, w, slots)
+                if key not in cache:
+                    cache.clear()
+                    cache[key] = ([torch.empty((h, w, 3), dtype=torch.uint8).pin_memory() for _ in range(slots)],
+                                  [torch.empty((h * s, w * s, 3), dtype=torch.uint8).pin_memory() for _ in range(slots)],
+                                  [torch.empty((h, w, 3), dtype=torch.uint8, device=dev) for _ in range(slots)],
+                                  [torch.empty((h * s, w * s, 3), dtype=torch.uint8, device=dev) for _ in range(slots)])
+                pin_in, pin_out, d_in, d_out = cache[key]
+            elif tuple(pin_in[0].shape) != f.shape:
+                raise ValueError("upscale_stream: all frames of a stream must have the same size")
+            k = n % slots
+            yield from drain(depth)           # frees pinned slot k (its download was ``slots`` frames ago)
+            pin_in[k].numpy()[...] = f
+            with torch.cuda.stream(up):
+                if ev_in_free[k] is not None:
+                    up.wait_event(ev_in_free[k])
+                d_in[k].copy_(pin_in[k], non_blocking=True)
+                ev_up = torch.cuda.Event()
+                ev_up.record(up)
+            with torch.cuda.stream(comp):
+                comp.wait_event(ev_up)
+                if ev_out_free[k] is not None:
+                    comp.wait_event(ev_out_free[k])
+                self.upscale_device(d_in[k], out=d_out[k], stream=comp.cuda_stream)
+                ev_c = torch.cuda.Event()
+                ev_c.record(comp)
+                ev_in_free[k] = ev_c
+            with torch.cuda.stream(down):
+                down.wait_event(ev_c)
+                pin_out[k].copy_(d_out[k], non_blocking=True)
+                ev_d = torch.cuda.Event()
+                ev_d.record(down)
+                ev_out_free[k] = ev_d
+            pending.append((k, ev_d))
+        yield from drain(0)
+
     # -- introspection ------------------------------------------------------------------------------
     def flops(self, height: int, width: int) -> float:
         return float(self._lib.fw_rrdbnet_flops(self._h, height, width))
