@@ -261,20 +261,22 @@ def test_enhance_frame_pytorch_roundtrip(hip_lib, tmp_path, monkeypatch):
     R.clear_upsampler_cache()
 
 
-def test_full_size_properties_1080p_x4(hip_lib):
-    """BASELINE size (1920x1080 -> 7680x4320, 6-block model to keep the test short): properties that need no oracle.
+@pytest.mark.parametrize("H,W,y0,x0", [(1080, 1920, 400, 800), (2160, 3840, 1900, 3500)])
+def test_full_size_properties_x4(hip_lib, H, W, y0, x0):
+    """BASELINE size (1920x1080 -> 7680x4320) and 4K (3840x2160 -> 15360x8640: 46 GB of workspace, byte offsets beyond
+    2^32), 6-block model to keep the test short: properties that need no oracle.
     (a) a crop far from the borders equals the same crop upscaled on its own with enough context (receptive field of
     the 6-block net + tail is < 100 px), (b) determinism."""
     nb = 6
     sd = synthetic_rrdbnet_state(nb, 4, seed=99)
     eng = R.RRDBNetEngine(nb, 4, "bf16")
     eng.load_state_dict(sd)
-    frame = synthetic_frames(1, 1080, 1920, seed=2)[0]
+    frame = synthetic_frames(1, H, W, seed=2)[0]
     t = torch.from_numpy(frame).cuda()
     full = eng.upscale_device(t)
     torch.cuda.synchronize()
-    assert tuple(full.shape) == (4320, 7680, 3)
-    y0, x0, sz, ctx = 400, 800, 64, 100
+    assert tuple(full.shape) == (4 * H, 4 * W, 3)
+    sz, ctx = 64, 100
     crop = np.ascontiguousarray(frame[y0 - ctx:y0 + sz + ctx, x0 - ctx:x0 + sz + ctx])
     small = eng.upscale(crop)[ctx * 4:(ctx + sz) * 4, ctx * 4:(ctx + sz) * 4]
     big = full[y0 * 4:(y0 + sz) * 4, x0 * 4:(x0 + sz) * 4].cpu().numpy()
