@@ -261,6 +261,31 @@ def test_enhance_frame_pytorch_roundtrip(hip_lib, tmp_path, monkeypatch):
     R.clear_upsampler_cache()
 
 
+def test_baseline_config0_x2_on_eight_256x256_frames(hip_lib, tmp_path, monkeypatch):
+    """BASELINE.json configs[0]: Real-ESRGAN x2 (RealESRGAN_x2plus, 23 blocks) on 8 synthetic 256x256 frames through the
+    reference's file boundary (`enhance_frame_pytorch`, one PNG in, one PNG out).  Every frame must come back 512x512;
+    two of them are checked against the fp32 CPU oracle (PSNR >= 50 dB, the north-star bar, bf16 operands)."""
+    from PIL import Image
+    monkeypatch.setenv("FRAMEWRIGHT_AMD_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("FRAMEWRIGHT_MODEL_DIR", str(tmp_path / "nomodels"))
+    frames = synthetic_frames(8, 256, 256, seed=17)
+    cfg = R.PyTorchESRGANConfig(model_name="RealESRGAN_x2plus", scale_factor=2, dtype="bf16")
+    outs = []
+    for i, f in enumerate(frames):
+        src, dst = tmp_path / f"frame_{i + 1:08d}.png", tmp_path / f"out_{i + 1:08d}.png"
+        Image.fromarray(f[:, :, ::-1]).save(src)
+        ok, msg = R.enhance_frame_pytorch(src, dst, cfg)
+        assert ok and msg is None
+        outs.append(np.asarray(Image.open(dst))[:, :, ::-1])
+        assert outs[-1].shape == (512, 512, 3)
+    sd = synthetic_rrdbnet_state(23, 2)      # the seeded weights FRAMEWRIGHT_AMD_SYNTHETIC_WEIGHTS substitutes
+    for i in (0, 5):
+        want = _oracle_rgb_f32(sd, frames[i], 23, 2)
+        want_u8 = np.rint(np.clip(want, 0, 1) * 255.0).astype(np.uint8)[:, :, ::-1]
+        assert _psnr_u8(outs[i], want_u8) >= 50.0
+    R.clear_upsampler_cache()
+
+
 @pytest.mark.parametrize("H,W,y0,x0", [(1080, 1920, 400, 800), (2160, 3840, 1900, 3500)])
 def test_full_size_properties_x4(hip_lib, H, W, y0, x0):
     """BASELINE size (1920x1080 -> 7680x4320) and 4K (3840x2160 -> 15360x8640: 46 GB of workspace, byte offsets beyond
