@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""What the matrix cores sustain on random bf16 data with nothing else in the way (csrc/diag_mfma.hip): TFLOP/s and the
+clock the chip holds, for both MFMA shapes, 2 waves per SIMD on every CU.  Context for roofline.frac, which is quoted
+against the 2.5 PFLOP/s spec figure."""
+import ctypes as C, json, sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from framewright_amd import build as B
+B.build()
+from framewright_amd import _lib
+lib = _lib.load()
+lib.fw_debug_mfma_peak.restype = C.c_int
+lib.fw_debug_mfma_peak.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_ulonglong)]
+res = {}
+import os
+BL = [int(x) for x in os.environ.get("FW_PEAK_BLOCKS", "256").split(",")]
+for blocks in BL:
+  for shape, per_iter, flop in ((16, 16, 16 * 16 * 32 * 2), (32, 8, 32 * 32 * 16 * 2)):
+    iters = 100000
+    ms, clk = C.c_float(), (C.c_ulonglong * 2)()
+    assert lib.fw_debug_mfma_peak(shape, blocks, iters, C.byref(ms), clk) == 0
+    total = blocks * 8 * iters * per_iter * flop
+    res[f"mfma_{shape}_b{blocks}"] = {"ms": ms.value, "tflops": total / (ms.value * 1e-3) / 1e12,
+                            "clock_ghz": clk[0] / max(clk[1], 1) * 0.1,
+                            # wave 0 of a workgroup is the OLDER wave of its SIMD: it wins every MFMA arbitration, runs at the
+                            # full rate and retires after about half of the launch (its partner then runs alone)
+                            "older_wave_ms": clk[1] / blocks / 1e5,
+                            "older_wave_cycles_per_mfma": clk[0] / blocks / (iters * per_iter)}
+print(json.dumps(res))
