@@ -234,10 +234,15 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
 #define FW_DMA_SLOT_W 2
 #define FW_DMA_SLOT_A 6
 #endif
+#ifndef FW_DMA_SLOT_W2   // the younger half of the workgroup (waves NWAVES/2..): same slots unless told otherwise
+#define FW_DMA_SLOT_W2 FW_DMA_SLOT_W
+#define FW_DMA_SLOT_A2 FW_DMA_SLOT_A
+#endif
+            const bool young = wave >= NWAVES / 2;
             auto dma_slot = [&](int d) {
-                if (d == FW_DMA_SLOT_W) {
+                if (d == (young ? FW_DMA_SLOT_W2 : FW_DMA_SLOT_W)) {
                     if (do_w) issue_w(c1, (n + 1) & 1);
-                } else if (d == FW_DMA_SLOT_A) {
+                } else if (d == (young ? FW_DMA_SLOT_A2 : FW_DMA_SLOT_A)) {
                     if (do_a) issue_act();
                 }
             };
