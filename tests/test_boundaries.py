@@ -82,3 +82,40 @@ def test_backends_and_plugins_end_to_end(hip_lib, tmp_path, monkeypatch):
     proc = B.RealESRGANProcessor("realesrgan-x4plus-anime", 4, 0)
     assert proc.process_frame(str(src / "frame_00000002.png"), str(tmp_path / "p.png"))
     b.clear_cache()
+
+
+def test_rocm_compute_backend_interface():
+    """`HipRocmBackend` has every abstract method of the reference's `Backend` ABC (infrastructure/gpu/backends/base.py:
+    89-205) and behaves like it when nothing is loaded."""
+    from framewright_amd import backends as B
+    for m in ("backend_type", "name", "is_initialized", "initialize", "cleanup", "get_capabilities", "allocate_memory",
+              "free_memory", "get_memory_info", "load_model", "unload_model", "run_inference", "__enter__", "__exit__"):
+        assert hasattr(B.HipRocmBackend, m), m
+    b = B.HipRocmBackend(device_id=0)
+    assert b.backend_type == "rocm" and not b.is_initialized
+    assert b.load_model("RealESRGAN_x4plus") is False                 # not initialised
+    with pytest.raises(ValueError, match="not loaded"):
+        b.run_inference("RealESRGAN_x4plus", np.zeros((4, 4, 3), np.uint8))
+    caps = B.BackendCapabilities(name="x")
+    assert set(caps.to_dict()) == {"name", "backend_type", "vendor", "supports_fp16", "supports_int8", "max_memory_mb", "max_batch_size"}
+
+
+@pytest.mark.gpu
+def test_rocm_compute_backend_runs_models(hip_lib, tmp_path, monkeypatch):
+    from framewright_amd import backends as B, realesrgan as R
+    from framewright_amd.synth import synthetic_frames
+    monkeypatch.setenv("FRAMEWRIGHT_AMD_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("FRAMEWRIGHT_MODEL_DIR", str(tmp_path / "nomodels"))
+    f0, f1 = synthetic_frames(2, 32, 48, seed=3)
+    with B.HipRocmBackend(0) as b:
+        assert b.is_initialized and b.get_capabilities().max_memory_mb > 100000 and b.allocate_memory(1024)
+        assert b.load_model("RealESRGAN_x4plus_anime_6B") and b.load_model("rife-v4.6") and not b.load_model("no-such-model")
+        up = b.run_inference("RealESRGAN_x4plus_anime_6B", f0)
+        assert up.shape == (128, 192, 3) and up.dtype == np.uint8
+        mid = b.run_inference("rife-v4.6", (f0, f1))
+        assert mid.shape == f0.shape
+        b.unload_model("rife-v4.6")
+        with pytest.raises(ValueError):
+            b.run_inference("rife-v4.6", (f0, f1))
+    assert not b.is_initialized
+    R.clear_upsampler_cache()

@@ -249,6 +249,133 @@ def make_device_process_func(config: Optional[R.PyTorchESRGANConfig] = None):
     return process_func
 
 
+# ---- compute-backend ABC (infrastructure/gpu/backends/base.py:65-215) ----------------------------------------------
+@dataclass
+class BackendCapabilities:
+    """infrastructure/gpu/backends/base.py:28-62 (backend_type / vendor as their string values: the enums live in the
+    reference's detector module)."""
+    name: str
+    backend_type: str = "rocm"
+    vendor: str = "amd"
+    supports_fp16: bool = True
+    supports_fp32: bool = True
+    supports_int8: bool = False
+    supports_dynamic_shapes: bool = True
+    supports_batching: bool = True
+    max_memory_mb: int = 0
+    recommended_memory_mb: int = 0
+    max_batch_size: int = 32
+    max_tile_size: int = 1024
+    supported_models: List[str] = field(default_factory=list)
+
+    def to_dict(self) -> dict:
+        return {"name": self.name, "backend_type": self.backend_type, "vendor": self.vendor,
+                "supports_fp16": self.supports_fp16, "supports_int8": self.supports_int8,
+                "max_memory_mb": self.max_memory_mb, "max_batch_size": self.max_batch_size}
+
+
+class HipRocmBackend:
+    """The reference's `Backend` interface (initialize / cleanup / get_capabilities / allocate_memory / free_memory /
+    get_memory_info / load_model / unload_model / run_inference, context manager) for MI355X.  The reference registers no
+    ROCm backend (`_backend_registry`, base.py:665-670, has CUDA / Metal / Vulkan / CPU) and its CUDA one is a stub whose
+    `run_inference` returns its input; here `load_model` builds the engine for the named model and `run_inference` runs it:
+
+      Real-ESRGAN names (`RealESRGAN_x4plus`, ...): inputs = BGR uint8 frame           -> upscaled BGR uint8 frame
+      "nafnet" / "restormer":                       inputs = BGR uint8 frame           -> denoised BGR uint8 frame
+      "rife-v4.6":                                  inputs = (frame0, frame1[, t=0.5]) -> interpolated BGR uint8 frame
+    """
+
+    backend_type = "rocm"
+    name = "ROCm (MI355X HIP kernels)"
+
+    def __init__(self, device_id: int = 0):
+        self.device_id = int(device_id)
+        self._initialized = False
+        self._loaded_models: dict = {}
+
+    @property
+    def is_initialized(self) -> bool:
+        return self._initialized
+
+    def initialize(self) -> bool:
+        from . import _lib
+        try:
+            self._initialized = _lib.load().fw_device_count() > self.device_id
+        except _lib.FramewrightHipError:
+            self._initialized = False
+        return self._initialized
+
+    def cleanup(self) -> None:
+        for name in list(self._loaded_models):
+            self.unload_model(name)
+        self._initialized = False
+
+    def get_memory_info(self) -> dict:
+        import torch
+        free, total = torch.cuda.mem_get_info(self.device_id)
+        return {"total_mb": total / 2 ** 20, "used_mb": (total - free) / 2 ** 20, "free_mb": free / 2 ** 20}
+
+    def get_capabilities(self) -> BackendCapabilities:
+        mem = self.get_memory_info() if self._initialized else {"total_mb": 0.0}
+        return BackendCapabilities(name=self.name, max_memory_mb=int(mem["total_mb"]), recommended_memory_mb=int(mem["total_mb"] * 0.9),
+                                   max_tile_size=0, supported_models=list(R.RRDB_MODELS) + ["nafnet", "restormer", "rife-v4.6"])
+
+    def allocate_memory(self, size_mb: float) -> bool:
+        return self._initialized and self.get_memory_info()["free_mb"] >= size_mb   # engines size their own workspaces
+
+    def free_memory(self) -> None:
+        import torch
+        torch.cuda.empty_cache()
+
+    def load_model(self, model_name: str, model_path: Optional[Path] = None, **kwargs) -> bool:
+        if not self._initialized:
+            return False
+        dtype = kwargs.get("dtype", "bf16")
+        if model_name in R.RRDB_MODELS:
+            cfg = R.PyTorchESRGANConfig(model_name=model_name, gpu_id=self.device_id, dtype=dtype,
+                                        model_path=str(model_path) if model_path else None)
+            self._loaded_models[model_name] = ("sr", R.get_upsampler(cfg))
+        elif model_name in ("nafnet", "restormer"):
+            dn = T.TAPDenoiser(T.TAPDenoiseConfig(model=model_name, gpu_id=self.device_id, tile_size=kwargs.get("tile_size", 0),
+                                                  temporal_window=1, dtype=kwargs.get("dtype", "f16")),
+                               model_dir=Path(model_path).parent if model_path else None)
+            dn._load_model()
+            self._loaded_models[model_name] = ("denoise", dn)
+        elif model_name == "rife-v4.6":
+            from . import rife as RF
+            fi = RF.FrameInterpolator(model=model_name, gpu_id=self.device_id, dtype=kwargs.get("dtype", "f16"))
+            fi._get_engine()
+            self._loaded_models[model_name] = ("interp", fi)
+        else:
+            return False
+        return True
+
+    def unload_model(self, model_name: str) -> None:
+        kind, obj = self._loaded_models.pop(model_name, (None, None))
+        if kind == "denoise":
+            obj.clear_cache()
+        self.free_memory()
+
+    def run_inference(self, model_name: str, inputs, **kwargs):
+        if model_name not in self._loaded_models:
+            raise ValueError(f"Model {model_name} not loaded")           # base.py:346-347
+        kind, obj = self._loaded_models[model_name]
+        if kind == "sr":
+            return obj.enhance(inputs, outscale=kwargs.get("outscale"))[0]
+        if kind == "denoise":
+            return obj.denoise_clip([inputs])[0]
+        f0, f1 = inputs[0], inputs[1]
+        return obj._get_engine().interpolate(f0, f1, inputs[2] if len(inputs) > 2 else kwargs.get("timestep", 0.5))
+
+    def __enter__(self):
+        self.initialize()
+        return self
+
+    def __exit__(self, exc_type, exc_val, exc_tb):
+        self.cleanup()
+        return False
+
+
 def register_with_reference() -> List[str]:
     """Add the HIP backends to the reference's selector tables if ``framewright`` is importable.  On MI355X the
     reference's own auto-detection classifies any non-NVIDIA GPU as CPU/NCNN (denoising.py:222-277), so
@@ -264,6 +391,15 @@ def register_with_reference() -> List[str]:
         from framewright.processors.enhancement import denoising as dn  # type: ignore
         dn.Denoiser.BACKENDS["tap_hip"] = HipTAPDenoiserBackend
         done.append("Denoiser.BACKENDS['tap_hip']")
+    except Exception:  # noqa: BLE001
+        pass
+    try:   # the reference has a ROCM BackendType but registers no class for it (base.py:665-670)
+        from framewright.infrastructure.gpu.backends import base as gb  # type: ignore
+        from framewright.infrastructure.gpu.detector import BackendType  # type: ignore
+        cls = type("HipRocmBackend", (HipRocmBackend, gb.Backend), {"backend_type": property(lambda self: BackendType.ROCM),
+                                                                      "name": property(lambda self: HipRocmBackend.name)})
+        gb.register_backend(BackendType.ROCM, cls)
+        done.append("register_backend(BackendType.ROCM)")
     except Exception:  # noqa: BLE001
         pass
     return done
