@@ -177,6 +177,47 @@ def host_logic() -> None:
     print(f"wrote {dst} ({dst.stat().st_size / 1024:.0f} KiB); round_robin: {[r.get('error', 'ok') for r in rr]}")
 
 
+def tap_logic() -> None:
+    """Fixture set 3 — TAP temporal-window arithmetic and the motion-adaptive strength table, evaluated by the reference's
+    own code (processors/tap_denoise.py; it imports without cv2):
+      * ``TAPDenoiser._denoise_with_temporal_window`` (:490-534) on random uint8 frames, with the per-frame denoise step
+        replaced by the identity THROUGH ITS OWN INSTANCE ATTRIBUTE (the step needs a loaded network and cv2; the window
+        selection, the 1/(1+0.5|d|) weights, the float32 accumulate and the truncating cast are the reference's);
+      * ``MotionAdaptiveTAPDenoiser.get_motion_adjusted_strength`` (:878-904) for every MotionLevel x 4 configs;
+      * the config defaults and the MODEL_FILES / MODEL_VRAM tables.
+    -> tests/golden/tap_reference.npz + tests/golden/tap_reference.json"""
+    import json
+    t = load_reference("framewright.processors.tap_denoise")
+    rng = np.random.default_rng(20260104)
+    out, meta = {}, {"windows": []}
+    for n, window in ((7, 5), (3, 3), (9, 7), (4, 5), (1, 5)):
+        frames = [rng.integers(0, 256, size=(7, 9, 3), dtype=np.uint8) for _ in range(n)]
+        den = t.TAPDenoiser(t.TAPDenoiseConfig(temporal_window=window))
+        den._denoise_frame_tiled = lambda f: f          # identity per-frame step (instance attribute, reference code untouched)
+        key = f"n{n}_w{window}"
+        out[key + "_frames"] = np.stack(frames)
+        out[key + "_out"] = np.stack([den._denoise_with_temporal_window(frames, i) for i in range(n)])
+        meta["windows"].append({"key": key, "n": n, "window": window})
+    levels = list(t.MotionLevel)
+    table = []
+    for cfg in (dict(), dict(base_strength=1.0, motion_sensitivity=1.0), dict(base_strength=0.5, motion_sensitivity=0.25, static_boost=1.05,
+                                                                              motion_penalty=0.9), dict(base_strength=0.9, motion_sensitivity=0.0)):
+        m = t.MotionAdaptiveTAPDenoiser(t.MotionAdaptiveConfig(**cfg))
+        table.append({"config": cfg, "strength": {lv.value: m.get_motion_adjusted_strength(lv) for lv in levels}})
+    meta["motion_strength"] = table
+    c = t.TAPDenoiseConfig()
+    meta["config_defaults"] = {"model": c.model.value, "temporal_window": c.temporal_window, "strength": c.strength,
+                               "preserve_grain": c.preserve_grain, "half_precision": c.half_precision, "tile_size": c.tile_size,
+                               "tile_overlap": c.tile_overlap, "gpu_id": c.gpu_id, "batch_size": c.batch_size}
+    meta["model_files"] = {k.value: v for k, v in t.TAPDenoiser.MODEL_FILES.items()}
+    meta["model_vram"] = {k.value: v for k, v in t.TAPDenoiser.MODEL_VRAM.items()}
+    meta["motion_levels"] = [lv.value for lv in levels]
+    np.savez_compressed(ROOT / "tests" / "golden" / "tap_reference.npz", **out)
+    (ROOT / "tests" / "golden" / "tap_reference.json").write_text(json.dumps(meta, indent=1, sort_keys=True))
+    print("wrote tests/golden/tap_reference.{npz,json}")
+
+
 if __name__ == "__main__":
     main()
     host_logic()
+    tap_logic()

@@ -143,3 +143,42 @@ def test_denoise_frames_directory_contract(hip_lib, tmp_path, monkeypatch):
     assert sorted(p.name for p in dst.glob("*.png")) == [f"frame_{i:08d}.png" for i in (1, 2, 3)]
     assert seen == pytest.approx([1 / 3, 2 / 3, 1.0])
     dn.clear_cache()
+
+
+def test_temporal_average_matches_reference_run(hip_lib):
+    """The device temporal average against outputs of the reference's own `_denoise_with_temporal_window`
+    (tests/golden/tap_reference.npz: identity per-frame step, every centre index of five clip/window shapes)."""
+    import json
+    from pathlib import Path
+    g = Path(__file__).parent / "golden"
+    arrs, meta = np.load(g / "tap_reference.npz"), json.loads((g / "tap_reference.json").read_text())
+    for w in meta["windows"]:
+        frames = list(arrs[w["key"] + "_frames"])
+        want = arrs[w["key"] + "_out"]
+        d = T.TAPDenoiser(T.TAPDenoiseConfig(model="nafnet", temporal_window=w["window"]))
+        for i in range(w["n"]):
+            s, e, ws = T.temporal_window(w["n"], i, w["window"])
+            got = d._temporal_average_device([torch.from_numpy(x).cuda() for x in frames[s:e]], ws)
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(got.cpu().numpy(), want[i])
+
+
+def test_motion_adaptive_driver(hip_lib, tmp_path, monkeypatch):
+    from PIL import Image
+    monkeypatch.setenv("FRAMEWRIGHT_AMD_SYNTHETIC_WEIGHTS", "1")
+    src, dst = tmp_path / "in", tmp_path / "out"
+    src.mkdir()
+    frames = list(synthetic_frames(3, 48, 64, seed=9))
+    for i, f in enumerate(frames):
+        Image.fromarray(f[:, :, ::-1]).save(src / f"frame_{i + 1:08d}.png")
+    tap = T.TAPDenoiseConfig(model="nafnet", tile_size=0, temporal_window=3)
+    m = T.MotionAdaptiveTAPDenoiser(T.MotionAdaptiveConfig(base_strength=1.0, motion_sensitivity=1.0), tap, model_dir=tmp_path / "none")
+    res = m.denoise_frames_motion_aware(src, dst, [T.MotionLevel.STATIC, T.MotionLevel.EXTREME])     # third level defaults to MODERATE
+    assert res.frames_processed == 3 and res.frames_failed == 0
+    outs = [np.asarray(Image.open(dst / f"frame_{i + 1:08d}.png"))[:, :, ::-1] for i in range(3)]
+    full = T.TAPDenoiser(tap, model_dir=tmp_path / "none").denoise_clip(frames)
+    assert np.array_equal(outs[0], full[0])                                          # STATIC at base 1.0 -> strength 1.0
+    for i, s in ((1, 0.4), (2, 0.8)):
+        want = tap_ref.strength_blend(frames[i], full[i], s)
+        assert np.array_equal(outs[i], want)
+    m.clear_cache()

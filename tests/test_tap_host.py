@@ -61,3 +61,46 @@ def test_unaccelerated_models_are_reported_unavailable():
     assert T.TAPDenoiseConfig().model is T.TAPModel.RESTORMER          # the reference's default (tap_denoise.py:110)
     d = T.TAPDenoiser(T.TAPDenoiseConfig(model=T.TAPModel.TAP))
     assert d.is_available() is False
+
+
+# ---- pinned on outputs of the reference's own code (tests/golden/tap_reference.*, oracle/gen_golden.py tap_logic) ----
+def _tap_golden():
+    import json
+    from pathlib import Path
+    g = Path(__file__).parent / "golden"
+    return np.load(g / "tap_reference.npz"), json.loads((g / "tap_reference.json").read_text())
+
+
+def test_oracle_temporal_window_matches_reference_run():
+    """oracle/tap_ref.py's window selection, weights, float32 accumulate and truncating cast against what the reference's
+    `_denoise_with_temporal_window` returned in the build container (identity per-frame step)."""
+    arrs, meta = _tap_golden()
+    identity = lambda t: t
+    for w in meta["windows"]:
+        frames = list(arrs[w["key"] + "_frames"])
+        want = arrs[w["key"] + "_out"]
+        for i in range(w["n"]):
+            s, e, ws = tap_ref.temporal_weights(w["n"], i, w["window"])
+            got = tap_ref.temporal_average(frames[s:e], ws) if w["window"] > 1 else frames[i]
+            np.testing.assert_array_equal(got, want[i])
+            s2, e2, ws2 = T.temporal_window(w["n"], i, w["window"])
+            assert (s2, e2) == (s, e) and np.allclose(ws2, ws, rtol=0, atol=0)
+
+
+def test_mirrors_match_reference_tables():
+    _, meta = _tap_golden()
+    c = T.TAPDenoiseConfig()
+    got = {"model": c.model.value, "temporal_window": c.temporal_window, "strength": c.strength, "preserve_grain": c.preserve_grain,
+           "half_precision": c.half_precision, "tile_size": c.tile_size, "tile_overlap": c.tile_overlap, "gpu_id": c.gpu_id,
+           "batch_size": c.batch_size}
+    assert got == meta["config_defaults"]
+    assert {k.value: v for k, v in T.TAPDenoiser.MODEL_FILES.items()} == meta["model_files"]
+    assert {k.value: v for k, v in T.TAPDenoiser.MODEL_VRAM.items()} == meta["model_vram"]
+    assert [lv.value for lv in T.MotionLevel] == meta["motion_levels"]
+    for row in meta["motion_strength"]:
+        m = T.MotionAdaptiveTAPDenoiser(T.MotionAdaptiveConfig(**row["config"]))
+        for lv in T.MotionLevel:
+            assert m.get_motion_adjusted_strength(lv) == row["strength"][lv.value]      # bit for bit
+    assert T.create_tap_denoiser("nafnet", strength=0.5).config.model is T.TAPModel.NAFNET
+    with pytest.raises(ValueError):
+        T.MotionAdaptiveConfig(base_strength=1.5)
