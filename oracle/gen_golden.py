@@ -217,7 +217,71 @@ def tap_logic() -> None:
     print("wrote tests/golden/tap_reference.{npz,json}")
 
 
+def tile_and_flow_logic() -> None:
+    """Fixture set 4 — more arithmetic of the reference run by the reference itself, with the steps that need a network or
+    cv2 replaced THROUGH INSTANCE ATTRIBUTES (the reference's source is untouched):
+      * ``TAPDenoiser._denoise_frame_tiled`` (tap_denoise.py:417-488): tile grid, np.linspace ramps on interior edges,
+        float32 accumulate, / max(weight, 1e-8), truncating cast — with `_preprocess_frame`, `_model`,
+        `_postprocess_frame` set to the identity, so a "denoised tile" is the input tile;
+      * ``TemporalDenoiser._denoise_simple`` (temporal_denoise.py:1582-1605) as is, and ``_denoise_with_flow`` (:1521-1580)
+        with a stand-in flow estimator object whose `estimate` returns given FlowFields (or raises for one neighbour) and
+        whose `warp_frame` returns given aligned frames: exp(-d*decay) * confidence, the 90th-percentile motion mask, the
+        float64 accumulate and the truncating cast are the reference's; cv2.remap itself is NOT exercised.
+    -> tests/golden/tile_flow_reference.npz + .json"""
+    import json
+    t = load_reference("framewright.processors.tap_denoise")
+    td = load_reference("framewright.processors.temporal_denoise")
+    rng = np.random.default_rng(20260105)
+    out, meta = {}, {"tiled": [], "flow": [], "simple": []}
+    ident = lambda x: x
+    for h, w, ts, ov in ((40, 56, 32, 8), (64, 64, 32, 8), (33, 47, 16, 4), (50, 36, 32, 16), (30, 30, 32, 8), (48, 80, 24, 1)):
+        frame = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        den = t.TAPDenoiser(t.TAPDenoiseConfig(tile_size=ts, tile_overlap=ov))
+        den._preprocess_frame, den._model, den._postprocess_frame = ident, ident, ident
+        key = f"tile_{h}x{w}_{ts}_{ov}"
+        out[key + "_in"], out[key + "_out"] = frame, den._denoise_frame_tiled(frame)
+        meta["tiled"].append({"key": key, "h": h, "w": w, "tile_size": ts, "overlap": ov})
+
+    class FakeEstimator:
+        def __init__(self, table, fail_id):
+            self.table, self.fail_id = table, fail_id
+
+        def estimate(self, frame, center):
+            if id(frame) == self.fail_id:
+                raise RuntimeError("flow failed")
+            return self.table[id(frame)][0]
+
+        def warp_frame(self, frame, flow, inverse=False):
+            return self.table[id(frame)][1]
+
+    for n, center, decay in ((5, 2, 0.5), (4, 0, 0.2), (3, 2, 1.0)):
+        h, w = 11, 13
+        frames = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for _ in range(n)]
+        table = {}
+        key = f"flow_n{n}_c{center}"
+        for i, f in enumerate(frames):
+            fx = (rng.standard_normal((h, w)) * 2).astype(np.float32)
+            fy = (rng.standard_normal((h, w)) * 2).astype(np.float32)
+            conf = rng.random((h, w)).astype(np.float32)
+            mag = np.sqrt(fx ** 2 + fy ** 2)
+            aligned = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+            table[id(f)] = (td.FlowField(fx, fy, mag, conf, 0, 1), aligned)
+            out[f"{key}_frame{i}"], out[f"{key}_aligned{i}"], out[f"{key}_conf{i}"], out[f"{key}_mag{i}"] = f, aligned, conf, mag
+        fail = (center + 1) % n
+        d = td.TemporalDenoiser(td.TemporalDenoiseConfig(temporal_weight_decay=decay))
+        d._flow_estimator = FakeEstimator(table, id(frames[fail]))
+        window = [(i, f) for i, f in enumerate(frames)]
+        out[key + "_out"] = d._denoise_with_flow(frames[center], center, window)
+        meta["flow"].append({"key": key, "n": n, "center": center, "decay": decay, "failing": fail})
+        out[key + "_simple"] = d._denoise_simple(frames[n // 2], window)
+        meta["simple"].append({"key": key, "n": n, "decay": decay})
+    np.savez_compressed(ROOT / "tests" / "golden" / "tile_flow_reference.npz", **out)
+    (ROOT / "tests" / "golden" / "tile_flow_reference.json").write_text(json.dumps(meta, indent=1, sort_keys=True))
+    print("wrote tests/golden/tile_flow_reference.{npz,json}")
+
+
 if __name__ == "__main__":
     main()
     host_logic()
     tap_logic()
+    tile_and_flow_logic()

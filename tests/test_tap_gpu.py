@@ -182,3 +182,34 @@ def test_motion_adaptive_driver(hip_lib, tmp_path, monkeypatch):
         want = tap_ref.strength_blend(frames[i], full[i], s)
         assert np.array_equal(outs[i], want)
     m.clear_cache()
+
+
+def test_tile_blend_matches_reference_run(hip_lib):
+    """The device crop / ramp-blend / finish kernels against outputs of the reference's own `_denoise_frame_tiled` (identity
+    pre / model / post steps; tests/golden/tile_flow_reference.npz)."""
+    import json
+    from pathlib import Path
+    g = Path(__file__).parent / "golden"
+    arrs, meta = np.load(g / "tile_flow_reference.npz"), json.loads((g / "tile_flow_reference.json").read_text())
+
+    class Identity:
+        device_id = 0
+
+        def denoise_device(self, frame, out=None, out_rgb_f32=None, stream=None):
+            if out is None:
+                return frame.clone()
+            out.copy_(frame)
+            return out
+
+        def clone(self):
+            return Identity()
+
+        def close(self):
+            pass
+
+    for c in meta["tiled"]:
+        frame, want = arrs[c["key"] + "_in"], arrs[c["key"] + "_out"]
+        d = T.TAPDenoiser(T.TAPDenoiseConfig(model="nafnet", tile_size=c["tile_size"], tile_overlap=c["overlap"]), engine=Identity())
+        got = d._denoise_frame_tiled_device(torch.from_numpy(np.ascontiguousarray(frame)).cuda())
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(got.cpu().numpy(), want)

@@ -104,3 +104,45 @@ def test_mirrors_match_reference_tables():
     assert T.create_tap_denoiser("nafnet", strength=0.5).config.model is T.TAPModel.NAFNET
     with pytest.raises(ValueError):
         T.MotionAdaptiveConfig(base_strength=1.5)
+
+
+def _tile_flow_golden():
+    import json
+    from pathlib import Path
+    g = Path(__file__).parent / "golden"
+    return np.load(g / "tile_flow_reference.npz"), json.loads((g / "tile_flow_reference.json").read_text())
+
+
+def test_oracle_tile_blend_matches_reference_run():
+    """oracle/tap_ref.py's tile grid, ramps, float32 accumulate and truncating cast against the reference's
+    `_denoise_frame_tiled` run with identity pre / model / post steps (tests/golden/tile_flow_reference.npz)."""
+    arrs, meta = _tile_flow_golden()
+    to_t = lambda f: torch.from_numpy(np.ascontiguousarray(f))
+    for c in meta["tiled"]:
+        frame, want = arrs[c["key"] + "_in"], arrs[c["key"] + "_out"]
+        # identity "model" on the oracle's own pre/post: postprocess(preprocess(tile)) returns the tile for uint8 input
+        got = tap_ref.denoise_frame_tiled(lambda t: t, frame, c["tile_size"], c["overlap"])
+        np.testing.assert_array_equal(got, want)
+
+
+def test_oracle_flow_accumulate_matches_reference_run():
+    """oracle/temporal_ref.py's weighting / accumulate / cast against the reference's `_denoise_with_flow` and
+    `_denoise_simple` (flow fields, aligned frames and one failing neighbour supplied through a stand-in estimator)."""
+    from oracle import temporal_ref
+    arrs, meta = _tile_flow_golden()
+    for c in meta["flow"]:
+        k, n = c["key"], c["n"]
+        frames = [arrs[f"{k}_frame{i}"] for i in range(n)]
+        # the oracle warps by itself; to feed it the recorded aligned frames, pass zero flow and the aligned frame as "frame"
+        window, flows = [], []
+        for i in range(n):
+            if i == c["center"]:
+                window.append(frames[i]); flows.append(None)
+            elif i == c["failing"]:
+                window.append(frames[i]); flows.append(None)
+            else:
+                z = np.zeros(frames[i].shape[:2], np.float32)
+                window.append(arrs[f"{k}_aligned{i}"])
+                flows.append(dict(flow_x=z, flow_y=z, magnitude=arrs[f"{k}_mag{i}"], confidence=arrs[f"{k}_conf{i}"]))
+        np.testing.assert_array_equal(temporal_ref.denoise_with_flow(c["center"], window, flows, c["decay"]), arrs[k + "_out"])
+        np.testing.assert_array_equal(temporal_ref.denoise_simple(frames, c["decay"]), arrs[k + "_simple"])

@@ -58,3 +58,27 @@ def test_denoise_simple_bit_exact_and_missing_flow_estimator(hip_lib):
     # no estimator: every neighbour falls back to the unaligned frame with the temporal weight only, as in the reference
     got = acc.denoise_with_flow(2, frames)
     np.testing.assert_array_equal(got, ref.denoise_with_flow(2, frames, [None] * 5, 0.5))
+
+
+def test_flow_accumulate_matches_reference_run(hip_lib):
+    """The device accumulate against outputs of the reference's own `_denoise_with_flow` / `_denoise_simple`
+    (tests/golden/tile_flow_reference.npz; the aligned frames are the recorded ones, so cv2.remap is not involved)."""
+    import json
+    from pathlib import Path
+    g = Path(__file__).parent / "golden"
+    arrs, meta = np.load(g / "tile_flow_reference.npz"), json.loads((g / "tile_flow_reference.json").read_text())
+    for c in meta["flow"]:
+        k, n = c["key"], c["n"]
+        frames = [arrs[f"{k}_frame{i}"] for i in range(n)]
+        window = [frames[i] if i in (c["center"], c["failing"]) else arrs[f"{k}_aligned{i}"] for i in range(n)]
+        z = np.zeros(frames[0].shape[:2], np.float32)
+        by_id = {id(window[i]): TD.FlowField(z, z, arrs[f"{k}_mag{i}"], arrs[f"{k}_conf{i}"]) for i in range(n)}
+
+        def flow_fn(frame, center, by_id=by_id, bad=window[c["failing"]]):
+            if frame is bad:
+                raise RuntimeError("flow failed")
+            return by_id[id(frame)]
+
+        acc = TD.DeviceTemporalAccumulator(temporal_weight_decay=c["decay"], flow_fn=flow_fn)
+        np.testing.assert_array_equal(acc.denoise_with_flow(c["center"], window), arrs[k + "_out"])
+        np.testing.assert_array_equal(acc.denoise_simple(frames), arrs[k + "_simple"])
