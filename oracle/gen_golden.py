@@ -280,8 +280,67 @@ def tile_and_flow_logic() -> None:
     print("wrote tests/golden/tile_flow_reference.{npz,json}")
 
 
+def interfaces() -> None:
+    """Fixture set 5 — the interfaces the drop-in mirrors must reproduce, read off the reference's own classes with
+    `inspect` / `dataclasses` (no arithmetic): abstract-method sets, parameter names of the public methods, dataclass field
+    names and defaults.  -> tests/golden/interfaces.json"""
+    import dataclasses
+    import enum
+    import inspect
+    import json
+
+    def describe(cls):
+        d = {"abstract": sorted(getattr(cls, "__abstractmethods__", ())), "methods": {}}
+        for name, fn in inspect.getmembers(cls, predicate=inspect.isfunction):
+            if name.startswith("_") and name not in ("__init__",):
+                continue
+            d["methods"][name] = list(inspect.signature(fn).parameters)
+        for name, prop in inspect.getmembers(cls, lambda o: isinstance(o, property)):
+            d["methods"][name] = ["<property>"]
+        if dataclasses.is_dataclass(cls):
+            fields = {}
+            for f in dataclasses.fields(cls):
+                if f.default is not dataclasses.MISSING:
+                    v = f.default
+                elif f.default_factory is not dataclasses.MISSING:  # type: ignore[misc]
+                    v = f.default_factory()  # type: ignore[misc]
+                else:
+                    v = "<required>"
+                if isinstance(v, enum.Enum):
+                    v = v.value
+                if isinstance(v, Path):
+                    v = str(v)
+                fields[f.name] = v if isinstance(v, (int, float, str, bool, list, dict, type(None))) else repr(v)
+            d["fields"] = fields
+        return d
+
+    wanted = {
+        "framewright.processors.pytorch_realesrgan": ["PyTorchESRGANConfig"],
+        "framewright.processors.enhancement.super_resolution": ["SRBackend", "SRResult"],
+        "framewright.processors.enhancement.denoising": ["DenoiserBackend", "DenoiseResult"],
+        "framewright.processors.tap_denoise": ["TAPDenoiseConfig", "TAPDenoiseResult", "TAPDenoiser", "AutoTAPDenoiser",
+                                               "MotionAdaptiveConfig", "MotionAdaptiveTAPDenoiser"],
+        "framewright.plugins.base": ["ProcessorPlugin", "PluginMetadata"],
+        "framewright.infrastructure.gpu.backends.base": ["Backend", "BackendCapabilities"],
+        "framewright.processors.temporal_denoise": ["FlowField"],
+    }
+    out, failed = {}, {}
+    for mod, names in wanted.items():
+        try:
+            m = load_reference(mod)
+        except Exception as e:  # noqa: BLE001 - an ordinary import error of the snapshot (missing sibling package)
+            failed[mod] = f"{type(e).__name__}: {e}"
+            continue
+        for n in names:
+            out[f"{mod.rsplit('.', 1)[1]}.{n}"] = describe(getattr(m, n))
+    (ROOT / "tests" / "golden" / "interfaces.json").write_text(json.dumps({"classes": out, "not_importable": failed}, indent=1,
+                                                                           sort_keys=True))
+    print("wrote tests/golden/interfaces.json;", len(out), "classes;", "not importable:", failed)
+
+
 if __name__ == "__main__":
     main()
     host_logic()
     tap_logic()
     tile_and_flow_logic()
+    interfaces()

@@ -1,0 +1,77 @@
+"""The drop-in mirrors against the reference's own classes, as read off them with `inspect` / `dataclasses` in the build
+container (tests/golden/interfaces.json, oracle/gen_golden.py interfaces()): abstract-method sets, parameter names of the
+public methods (a mirror may accept MORE keyword parameters after the reference's, never fewer or renamed), dataclass field
+names and defaults."""
+import dataclasses
+import enum
+import inspect
+import json
+from pathlib import Path
+
+import pytest
+
+from framewright_amd import backends as B
+from framewright_amd import plugins as PL
+from framewright_amd import realesrgan as R
+from framewright_amd import tap_denoise as T
+from framewright_amd import temporal_denoise as TD
+
+GOLD = json.loads((Path(__file__).parent / "golden" / "interfaces.json").read_text())["classes"]
+
+MIRRORS = {
+    "pytorch_realesrgan.PyTorchESRGANConfig": R.PyTorchESRGANConfig,
+    "super_resolution.SRBackend": B.SRBackend,
+    "super_resolution.SRResult": B.SRResult,
+    "denoising.DenoiserBackend": B.DenoiserBackend,
+    "denoising.DenoiseResult": B.DenoiseResult,
+    "tap_denoise.TAPDenoiseConfig": T.TAPDenoiseConfig,
+    "tap_denoise.TAPDenoiseResult": T.TAPDenoiseResult,
+    "tap_denoise.TAPDenoiser": T.TAPDenoiser,
+    "tap_denoise.AutoTAPDenoiser": T.AutoTAPDenoiser,
+    "tap_denoise.MotionAdaptiveConfig": T.MotionAdaptiveConfig,
+    "tap_denoise.MotionAdaptiveTAPDenoiser": T.MotionAdaptiveTAPDenoiser,
+    "base.ProcessorPlugin": PL.ProcessorPlugin,
+    "base.PluginMetadata": PL.PluginMetadata,
+    "base.Backend": B.HipRocmBackend,
+    "base.BackendCapabilities": B.BackendCapabilities,
+    "temporal_denoise.FlowField": TD.FlowField,
+}
+
+
+def test_every_reference_class_has_a_mirror():
+    assert set(GOLD) == set(MIRRORS)
+
+
+@pytest.mark.parametrize("key", sorted(MIRRORS))
+def test_mirror_matches_reference_interface(key):
+    ref, cls = GOLD[key], MIRRORS[key]
+    # abstract methods: the reference's ABC mirrors declare the same set; concrete classes (HipRocmBackend) implement all of it
+    if key != "base.Backend" and ref["abstract"]:
+        assert set(ref["abstract"]) == set(getattr(cls, "__abstractmethods__", ())), key
+    for name, params in ref["methods"].items():
+        assert hasattr(cls, name), f"{key}.{name} missing"
+        if params == ["<property>"]:
+            continue
+        if name == "__init__" and dataclasses.is_dataclass(cls):
+            continue                                        # covered by the field comparison below
+        got = list(inspect.signature(getattr(cls, name)).parameters)
+        assert got[:len(params)] == params, f"{key}.{name}: {got} vs reference {params}"
+    if "fields" in ref:
+        assert dataclasses.is_dataclass(cls), key
+        mine = {f.name: f for f in dataclasses.fields(cls)}
+        extra_ok = {"pytorch_realesrgan.PyTorchESRGANConfig": {"dtype", "model_path"}, "tap_denoise.TAPDenoiseConfig": {"dtype"}}
+        assert set(ref["fields"]) <= set(mine) and set(mine) - set(ref["fields"]) <= extra_ok.get(key, set()), key
+        for fname, want in ref["fields"].items():
+            f = mine[fname]
+            if want == "<required>":
+                # FlowField's indices have defaults in the mirror (convenience); everything else required stays required
+                if not (key == "temporal_denoise.FlowField" and fname.startswith("frame_idx")) and \
+                        not (key == "base.BackendCapabilities" and fname in ("backend_type", "vendor")):
+                    assert f.default is dataclasses.MISSING and f.default_factory is dataclasses.MISSING, (key, fname)
+                continue
+            v = f.default if f.default is not dataclasses.MISSING else f.default_factory()
+            if isinstance(v, enum.Enum):
+                v = v.value
+            if isinstance(v, (set, frozenset)):
+                v = repr(set(v))
+            assert v == want, f"{key}.{fname}: {v!r} vs reference {want!r}"

@@ -49,6 +49,13 @@ except Exception:  # noqa: BLE001
         max_framewright_version: Optional[str] = None
         settings_schema: Dict[str, Any] = field(default_factory=dict)
 
+        def to_dict(self) -> Dict[str, Any]:  # plugins/base.py:79-96
+            return {"name": self.name, "version": self.version, "description": self.description, "author": self.author,
+                    "website": self.website, "license": self.license, "capabilities": [c.name for c in self.capabilities],
+                    "dependencies": self.dependencies, "python_packages": self.python_packages, "min_vram_mb": self.min_vram_mb,
+                    "recommended_vram_mb": self.recommended_vram_mb, "supports_cpu": self.supports_cpu,
+                    "supports_cuda": self.supports_cuda, "supports_mps": self.supports_mps}
+
     class ProcessorPlugin(ABC):  # plugins/base.py:99-250 (PluginBase + ProcessorPlugin)
         def __init__(self):
             self._initialized = False
@@ -85,6 +92,29 @@ except Exception:  # noqa: BLE001
         @property
         def settings(self) -> Dict[str, Any]:
             return self._settings
+
+        def update_settings(self, settings: Dict[str, Any]) -> None:  # plugins/base.py:151-158
+            self._settings.update(settings)
+            self._on_settings_changed(settings)
+
+        def _on_settings_changed(self, settings: Dict[str, Any]) -> None:
+            pass
+
+        def validate_requirements(self) -> List[str]:  # plugins/base.py:159-183: missing packages, then the VRAM floor
+            meta = self.get_metadata()
+            issues = []
+            for package in meta.python_packages:
+                try:
+                    __import__(package)
+                except ImportError:
+                    issues.append(f"Missing Python package: {package}")
+            if self._device.startswith("cuda") and meta.min_vram_mb > 0:
+                import torch
+                if torch.cuda.is_available():
+                    vram = torch.cuda.get_device_properties(_gpu_id(self._device)).total_memory / (1024 * 1024)
+                    if vram < meta.min_vram_mb:
+                        issues.append(f"Insufficient VRAM: {vram:.0f}MB < {meta.min_vram_mb}MB required")
+            return issues
 
         @abstractmethod
         def process_frame(self, frame: np.ndarray, frame_number: int, context: Optional[Dict[str, Any]] = None) -> np.ndarray: ...
