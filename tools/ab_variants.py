@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""A/B of conv-kernel variants on ONE box in ONE call (boxes differ by +-4 % on this path, so only same-box numbers compare).
+
+  python tools/ab_variants.py NAME[:SRCDIR][=FLAGS] ...
+
+Each variant recompiles csrc/conv3x3_mfma.hip and csrc/conv3x3_pair.hip (from SRCDIR when given: a directory holding
+alternative copies of csrc/, e.g. the previous commit's, exported under build/) with FW_EXTRA flags FLAGS, relinks the
+library with the other objects of the in-tree build, and times Real-ESRGAN x4 1080p frames in a child process.  The default
+library is rebuilt at the end.  Prints one line per variant: ms/frame, conv TFLOP/s, per-kernel-class averages.
+"""
+import json, os, subprocess, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from framewright_amd import build as B
+
+CHILD = r"""
+import json, sys, time
+sys.path.insert(0, %r)
+import torch
+from framewright_amd.realesrgan import RRDBNetEngine
+from framewright_amd.synth import synthetic_frames, synthetic_rrdbnet_state
+eng = RRDBNetEngine(23, 4, "bf16"); eng.load_state_dict(synthetic_rrdbnet_state(23, 4))
+d = torch.from_numpy(synthetic_frames(1, 1080, 1920, seed=2)[0]).cuda(); o = torch.empty((4320, 7680, 3), dtype=torch.uint8, device="cuda")
+for _ in range(3): eng.upscale_device(d, out=o)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+N = 8
+for _ in range(N): eng.upscale_device(d, out=o)
+torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / N * 1e3
+eng.profile_enable(True)
+for _ in range(2): eng.upscale_device(d, out=o)
+launches, conv_ms, conv_flops = eng.profile_read()
+print(json.dumps({"ms_per_frame": ms, "conv_tflops": conv_flops / conv_ms / 1e9, "checksum": int(o[::97, ::89].to(torch.int64).sum())}))
+"""
+
+
+def rebuild(srcdir: Path, flags: list[str]) -> None:
+    cc = B.hipcc()
+    B.build()  # the other objects
+    for name in ("conv3x3_mfma", "conv3x3_pair"):
+        src = srcdir / f"{name}.hip"
+        cmd = [cc, *flags, *B.CXXFLAGS, f"-I{B.INCLUDE}", f"-I{srcdir}", f"-I{B.CSRC}", "-c", str(src), "-o", str(B.OBJ_DIR / f"{name}.o")]
+        subprocess.run(cmd, check=True)
+    objs = [str(B.OBJ_DIR / (s.stem + ".o")) for s in B.sources()]
+    subprocess.run([cc, "-shared", "-fPIC", f"--offload-arch={B.ARCH}", "-fno-gpu-rdc", *objs, "-o", str(B.LIB_PATH)], check=True)
+
+
+def main():
+    for spec in sys.argv[1:]:
+        name, _, flags = spec.partition("=")
+        name, _, sd = name.partition(":")
+        srcdir = (ROOT / sd) if sd else B.CSRC
+        rebuild(srcdir, flags.split())
+        r = subprocess.run([sys.executable, "-c", CHILD % str(ROOT)], capture_output=True, text=True)
+        line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:]
+        print(f"{name:24s} {line}", flush=True)
+    rebuild(B.CSRC, [])
+
+
+if __name__ == "__main__":
+    main()

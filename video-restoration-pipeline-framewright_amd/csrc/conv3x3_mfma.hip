@@ -218,10 +218,14 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
         for (int c = 0; c < nch; ++c, ++n) {
             // item n has landed (each wave waits for its own DMAs, then the barrier) and every wave is done reading
             // the stages that are refilled during this item
-            if (NA == 3 && n + 1 < nitems)
-                FW_WAIT_VMCNT(ACT_ITERS);  //: activations(n+1) may stay in flight
-            else
-                FW_WAIT_VMCNT(0);
+            // A tile's first item after an epilogue does not wait: vmcnt counts stores too (gfx9), so a wait behind the
+            // epilogue's stores would sit out their round trip to memory; its DMAs were waited for before the epilogue.
+            if (c > 0 || t == t_lo) {
+                if (NA == 3 && n + 1 < nitems)
+                    FW_WAIT_VMCNT(ACT_ITERS);  //: activations(n+1) may stay in flight
+                else
+                    FW_WAIT_VMCNT(0);
+            }
             FW_STAMP(5);  // this wave's own DMAs
             __syncthreads();
             FW_STAMP(0);  // barrier
@@ -287,6 +291,12 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
         }
 
         // ---- epilogue (the DMA stream is already fetching the next tile) -----------------------------------------
+        // the next tile's first item (n) has been in flight for an item: wait for it here, ahead of the epilogue's stores
+        if (NA == 3 && n + 1 < nitems)
+            FW_WAIT_VMCNT(ACT_ITERS);
+        else
+            FW_WAIT_VMCNT(0);
+        FW_STAMP(5);
         if (dbg & 4) continue;
         if constexpr (EPI == EPI_IMAGE) {
             // output channels 0..2 = R,G,B: tile 0, registers j = 0..2 of the lanes with sl == 0
@@ -353,8 +363,7 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
                                 }
                             } else {
                                 if (p.act == 1) {
-#pragma unroll
-                                    for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.2f * o[j]);
+                                    o = lrelu4(o);
                                 } else if (p.act == 2) {  // PReLU, per-channel slopes in chan_scale (SRVGGNetCompact)
                                     const f32x4 sl4 = *reinterpret_cast<const f32x4*>(p.chan_scale + 16 * w + 4 * sl);
 #pragma unroll
@@ -377,8 +386,14 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
                 char* scr = reinterpret_cast<char*>(lds + ((n - 1) % NA) * ACT_REGION) + wave * 4352;
                 // pass 0: the typed output; pass 1 (64-channel convs feeding a split trunk): lo = T(y - T(y)) into out_lo
                 const int npass = (CT == 2 && p.out_lo) ? 2 : 1;
+                constexpr int LPP = 4 * CT;  // lanes per pixel (16 B each)
+                constexpr int PPI = 64 / LPP;
+                constexpr int NIT = 32 / PPI;
+                const int lane_px = lane / LPP, k = lane % LPP;
                 for (int pass = 0; pass < npass; ++pass) {
-                    T* outp = reinterpret_cast<T*>(pass ? p.out_lo : p.out);
+                    // store address = per-lane base (once per pass) + wave-uniform row / iteration offsets (scalar arithmetic)
+                    char* lane_base = reinterpret_cast<char*>(pass ? p.out_lo : p.out) +
+                                      ((long)lane_px * p.out_cstride + p.out_coff + (long)(k >> 2) * p.out_pstride + (k & 3) * 8) * 2;
 #pragma unroll
                     for (int row = 0; row < RPW; ++row) {
                         const int y = y0 + RPW * wave + row;
@@ -391,26 +406,24 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
                                 *reinterpret_cast<uint2*>(scr + (16 * ph + q) * PSTR + (16 * w + 4 * sl) * 2) =
                                     Op<T>::pack4(o[0], o[1], o[2], o[3]);
                             }
-                        constexpr int LPP = 4 * CT;  // lanes per pixel (16 B each)
-                        constexpr int PPI = 64 / LPP;
+                        uint4 v[NIT];  // all LDS reads first, then the stores
 #pragma unroll
-                        for (int it = 0; it < 32 / PPI; ++it) {
-                            const int px = it * PPI + lane / LPP;
-                            const int k = lane % LPP;
-                            uint4 v;
+                        for (int it = 0; it < NIT; ++it) {
+                            const int px = it * PPI + lane_px;
                             if constexpr (CT == 1) {
-                                v = *reinterpret_cast<const uint4*>(scr + px * PSTR + k * 16);
+                                v[it] = *reinterpret_cast<const uint4*>(scr + px * PSTR + k * 16);
                             } else {
                                 const uint2 lo = *reinterpret_cast<const uint2*>(scr + px * PSTR + k * 16);
                                 const uint2 hi = *reinterpret_cast<const uint2*>(scr + px * PSTR + k * 16 + 8);
-                                v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                                v[it] = make_uint4(lo.x, lo.y, hi.x, hi.y);
                             }
-                            const int x = x0 + px;
-                            if (y < p.H && x < p.W) {
-                                T* dst = outp + ((size_t)y * p.W + x) * p.out_cstride + p.out_coff + (k >> 2) * p.out_pstride +
-                                         (k & 3) * 8;
-                                *reinterpret_cast<uint4*>(dst) = v;
-                            }
+                        }
+                        if (y < p.H) {  // wave-uniform
+                            const long rowoff = ((long)y * p.W + x0) * p.out_cstride * 2;
+#pragma unroll
+                            for (int it = 0; it < NIT; ++it)
+                                if (x0 + it * PPI + lane_px < p.W)
+                                    *reinterpret_cast<uint4*>(lane_base + rowoff + (long)(it * PPI) * p.out_cstride * 2) = v[it];
                         }
                     }
                 }

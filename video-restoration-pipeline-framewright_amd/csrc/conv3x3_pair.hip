@@ -159,12 +159,19 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_kern
     // true for all but the border tiles (the emit phase is VALU-bound: two waves per SIMD convert at the same time).
     // copy-out lane plan: 64 lanes = 16 pixels x 4 physical slots, two passes per row; pixels 0 and 31 of the region are
     // the recompute ring, never stored
+    // The global address of a copy-out piece = a wave-uniform row base (scalar arithmetic) + a loop-constant 32-bit
+    // per-lane offset: the 64-bit per-lane multiplies this replaced were a third of the emit phase.
     const int co_k = lane & 3;
     bool co_ok[2];
+    int co_lds[2];        // piece index of the lane's piece inside a halo row
+    unsigned co_goff[2];  // byte offset from the row's compute-region origin in the output plane
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int cp = it * 16 + (lane >> 2);
+        const int hp = cp + 1;
         co_ok[it] = cp >= 1 && cp <= PAIR_TW;
+        co_lds[it] = hp * 4 + co_k;
+        co_goff[it] = (unsigned)((cp * p.out_cstride + (co_k ^ halo_swz(hp)) * 8) * 2);
     }
     auto emit = [&](int w0, uint4* xa, int oy, int ox, T* plane, bool zero_outside, auto interior_tag) {
         constexpr bool INTERIOR = decltype(interior_tag)::value;
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_kern
 #pragma unroll
                 for (int wl2 = 0; wl2 < 2; ++wl2) {
                     const f32x4 v = w0 ? acc[row][2 + wl2][ph] : acc[row][wl2][ph];
-                    f32x4 o = __builtin_elementwise_max(v, v * 0.2f);
+                    f32x4 o = lrelu4(v);
                     if (!INTERIOR && zero) o = f32x4{0.f, 0.f, 0.f, 0.f};
                     // channels 16*wl2 + 4*sl + j: slot 2*wl2 + (sl >> 1), bytes 8*(sl & 1)..
                     const int hp = cp + 1;
@@ -190,22 +197,26 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_kern
                 }
             }
         }
-        // copy-out: logical slot = physical ^ swizzle(px)
+        FW_STAMP(6);  // emit: convert + LDS writes
+        // copy-out: logical slot = physical ^ swizzle(px).  All LDS reads first (unconditional: they stay inside the tile),
+        // then the stores.
+        uint4 cv[RPW][2];
+#pragma unroll
+        for (int row = 0; row < RPW; ++row)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) cv[row][it] = xa[(RPW * wave + row + 1) * (HALO_W * 4) + co_lds[it]];
 #pragma unroll
         for (int row = 0; row < RPW; ++row) {
             const int cr = RPW * wave + row;
             const int gy = oy + cr;
             const bool row_ok = cr >= 1 && cr <= PAIR_TH && (INTERIOR || (unsigned)gy < (unsigned)p.H);  // wave-uniform
             if (!row_ok) continue;
+            char* rowbase = reinterpret_cast<char*>(plane) + ((long)gy * p.W + ox) * p.out_cstride * 2;  // wave-uniform
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
-                const int cp = it * 16 + (lane >> 2);  // pixel inside the compute region
-                const int hp = cp + 1;                  // halo-tile pixel
-                const uint4 v = xa[((cr + 1) * HALO_W + hp) * 4 + co_k];
-                const int s = co_k ^ halo_swz(hp);
-                const int gx = ox + cp;
+                const int gx = ox + it * 16 + (lane >> 2);
                 if (co_ok[it] && (INTERIOR || (unsigned)gx < (unsigned)p.W))
-                    *reinterpret_cast<uint4*>(plane + ((size_t)gy * p.W + gx) * p.out_cstride + s * 8) = v;
+                    *reinterpret_cast<uint4*>(rowbase + co_goff[it]) = cv[row][it];
             }
         }
     };
@@ -231,10 +242,13 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_kern
                 for (int ph = 0; ph < 2; ++ph) acc[row][w][ph] = bv;
         }
         // one pipeline item; BOTH = shared input chunk (feeds conv_a and conv_b), !BOTH = conv_b's x_a chunk
-        auto run_item = [&](int j, auto both_tag) {
+        // wait_dma: this wave's DMAs for the item are waited for here.  Not after an emit: gfx9's vmcnt counts stores too, so
+        // a vmcnt(0) behind the emit's stores waits for their round trip to memory.  The items that follow an emit (the x_a
+        // item; a tile's first item after the previous tile's x_b emit) have their DMAs waited for BEFORE that emit instead.
+        auto run_item = [&](int j, auto both_tag, bool wait_dma) {
             constexpr bool BOTH = decltype(both_tag)::value;
             FW_STAMP(BOTH ? 1 : 2);   // previous phase ends (compute of the previous item / emit)
-            if (!(FW_PAIR_DBG & 32)) FW_WAIT_VMCNT(0);
+            if (wait_dma && !(FW_PAIR_DBG & 32)) FW_WAIT_VMCNT(0);
             FW_STAMP(5);              // waiting for this wave's own DMAs
             if (!(FW_PAIR_DBG & 16)) __syncthreads();
             FW_STAMP(0);              // barrier
@@ -275,9 +289,17 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_kern
             ++n;
         };
         FW_STAMP(4);  // tile setup (bias -> accumulators)
-        for (int j = 0; j < na; ++j) run_item(j, std::true_type{});
+        bool wait_dma = t == t_lo;  // (a variable, and no unrolling: hipcc otherwise peels a second copy of the item body)
+#pragma clang loop unroll(disable)
+        for (int j = 0; j < na; ++j) {
+            run_item(j, std::true_type{}, wait_dma);
+            wait_dma = true;
+        }
         FW_STAMP(1);
         // conv_a done.  Every wave must be finished with the last chunk's stage before it becomes the x_a tile.
+        // In flight: the x_a item's weights and the next tile's first chunk, both issued an item ago.
+        if (!(FW_PAIR_DBG & 32)) FW_WAIT_VMCNT(0);
+        FW_STAMP(5);
         __syncthreads();
         FW_STAMP(0);
         // the whole 16x32 compute region inside the image?  (uniform; false only for border tiles)
@@ -289,9 +311,12 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_kern
                 emit(0, lds + ((qd - 1) & 1) * ACT_REGION, oy, ox, reinterpret_cast<T*>(p.out_a), true, std::false_type{});
         }
         FW_STAMP(3);  // emit of x_a
-        run_item(na, std::false_type{});
+        run_item(na, std::false_type{}, false);
         FW_STAMP(2);  // x_a item compute
-        // conv_b done: every wave has finished reading the x_a tile before it is reused as the store-transpose buffer
+        // conv_b done: every wave has finished reading the x_a tile before it is reused as the store-transpose buffer.
+        // In flight: the x_a stores (an item old) and the next tile's first weights.
+        if (!(FW_PAIR_DBG & 32)) FW_WAIT_VMCNT(0);
+        FW_STAMP(5);
         __syncthreads();
         FW_STAMP(0);
         if (!(FW_PAIR_DBG & 4)) {
