@@ -375,60 +375,44 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
                         }
             }
             FW_STAMP(3);  // fp32-side epilogue
-            // (2) typed NHWC output: transpose each row through LDS so that one wave-instruction stores whole
-            //     pixels (16 B per lane, contiguous).  Scratch = a private 4352-byte slice of the activation stage just
-            //     consumed (every wave has finished reading it after the barrier; it is refilled only after the next
-            //     chunk barrier).
+            // (2) typed NHWC output, 16 B per lane straight from the accumulators: v_permlane16_swap pairs the 8-byte fragments
+            //     of two neighbouring 16-channel tiles so that a lane ends up with one whole 8-channel slot of its pixel
+            //     (ls; conv3x3_pair.hip has the lane map) and four lanes store a pixel's 64 contiguous bytes.  No transpose
+            //     through LDS and no barrier: the older wave of a SIMD stores while the younger one still runs MFMAs.
             if (p.out) {
-                constexpr int PSTR = CT == 1 ? 80 : 136;   // bytes per pixel in scratch (padded: conflict-free writes)
-                __syncthreads();
-                FW_STAMP(0);
-                char* scr = reinterpret_cast<char*>(lds + ((n - 1) % NA) * ACT_REGION) + wave * 4352;
                 // pass 0: the typed output; pass 1 (64-channel convs feeding a split trunk): lo = T(y - T(y)) into out_lo
                 const int npass = (CT == 2 && p.out_lo) ? 2 : 1;
-                constexpr int LPP = 4 * CT;  // lanes per pixel (16 B each)
-                constexpr int PPI = 64 / LPP;
-                constexpr int NIT = 32 / PPI;
-                const int lane_px = lane / LPP, k = lane % LPP;
+                const int ls = (sl & 1) ? 2 + (sl >> 1) : (sl >> 1);
                 for (int pass = 0; pass < npass; ++pass) {
-                    // store address = per-lane base (once per pass) + wave-uniform row / iteration offsets (scalar arithmetic)
+                    // store address = per-lane base (once per pass) + wave-uniform row / half-row / plane offsets (scalar)
                     char* lane_base = reinterpret_cast<char*>(pass ? p.out_lo : p.out) +
-                                      ((long)lane_px * p.out_cstride + p.out_coff + (long)(k >> 2) * p.out_pstride + (k & 3) * 8) * 2;
+                                      ((long)q * p.out_cstride + p.out_coff + ls * 8) * 2;
 #pragma unroll
                     for (int row = 0; row < RPW; ++row) {
                         const int y = y0 + RPW * wave + row;
+                        if (y >= p.H) continue;  // wave-uniform
+                        const long rowoff = ((long)y * p.W + x0) * p.out_cstride * 2;
 #pragma unroll
-                        for (int w = 0; w < NW; ++w)
+                        for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
-                            for (int ph = 0; ph < 2; ++ph) {
-                                f32x4 o = acc[row][w][ph];
-                                if (pass) o = o - Op<T>::unpack4(Op<T>::pack4(o[0], o[1], o[2], o[3]));
-                                *reinterpret_cast<uint2*>(scr + (16 * ph + q) * PSTR + (16 * w + 4 * sl) * 2) =
-                                    Op<T>::pack4(o[0], o[1], o[2], o[3]);
+                            for (int c2 = 0; c2 < CT; ++c2) {
+                                f32x4 oa = acc[row][2 * c2][ph], ob = acc[row][2 * c2 + 1][ph];
+                                if (pass) {
+                                    oa = oa - Op<T>::unpack4(Op<T>::pack4(oa[0], oa[1], oa[2], oa[3]));
+                                    ob = ob - Op<T>::unpack4(Op<T>::pack4(ob[0], ob[1], ob[2], ob[3]));
+                                }
+                                const uint2 pa = Op<T>::pack4(oa[0], oa[1], oa[2], oa[3]);
+                                const uint2 pb = Op<T>::pack4(ob[0], ob[1], ob[2], ob[3]);
+                                const u32x2 sx = __builtin_amdgcn_permlane16_swap(pa.x, pb.x, false, false);
+                                const u32x2 sy = __builtin_amdgcn_permlane16_swap(pa.y, pb.y, false, false);
+                                if (x0 + 16 * ph + q < p.W)
+                                    *reinterpret_cast<uint4*>(lane_base + rowoff + (long)(16 * ph) * p.out_cstride * 2 +
+                                                              (long)c2 * p.out_pstride * 2) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
                             }
-                        uint4 v[NIT];  // all LDS reads first, then the stores
-#pragma unroll
-                        for (int it = 0; it < NIT; ++it) {
-                            const int px = it * PPI + lane_px;
-                            if constexpr (CT == 1) {
-                                v[it] = *reinterpret_cast<const uint4*>(scr + px * PSTR + k * 16);
-                            } else {
-                                const uint2 lo = *reinterpret_cast<const uint2*>(scr + px * PSTR + k * 16);
-                                const uint2 hi = *reinterpret_cast<const uint2*>(scr + px * PSTR + k * 16 + 8);
-                                v[it] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                            }
-                        }
-                        if (y < p.H) {  // wave-uniform
-                            const long rowoff = ((long)y * p.W + x0) * p.out_cstride * 2;
-#pragma unroll
-                            for (int it = 0; it < NIT; ++it)
-                                if (x0 + it * PPI + lane_px < p.W)
-                                    *reinterpret_cast<uint4*>(lane_base + rowoff + (long)(it * PPI) * p.out_cstride * 2) = v[it];
-                        }
                     }
                 }
             }
-            FW_STAMP(6);  // typed store through LDS
+            FW_STAMP(6);  // typed store
         }
     }
     if constexpr (CT == 2 && (EPI == EPI_RESIDUAL || SPLIT)) FW_STAMP_FLUSH(p.stamps);

@@ -153,58 +153,36 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_kern
 
     f32x4 acc[RPW][NW][2];  // [row][tile][16-pixel half]: pixel 16*ph + q, channels 16*(w & 1) + 4*sl + j of conv w >> 1
 
-    // tiles w0, w0+1 (+bias already inside) -> LeakyReLU -> typed -> tile in LDS at `xa` (halo format, zero outside the image
-    // when `zero_outside`), then the wave copies its own rows' valid interior to the global plane with 16-B/lane stores.
-    // INTERIOR (compile time): the whole compute region lies inside the image, so no per-pixel image tests are needed -
-    // true for all but the border tiles (the emit phase is VALU-bound: two waves per SIMD convert at the same time).
-    // copy-out lane plan: 64 lanes = 16 pixels x 4 physical slots, two passes per row; pixels 0 and 31 of the region are
-    // the recompute ring, never stored
-    // The global address of a copy-out piece = a wave-uniform row base (scalar arithmetic) + a loop-constant 32-bit
-    // per-lane offset: the 64-bit per-lane multiplies this replaced were a third of the emit phase.
-    const int co_k = lane & 3;
-    bool co_ok[2];
-    int co_lds[2];        // piece index of the lane's piece inside a halo row
-    unsigned co_goff[2];  // byte offset from the row's compute-region origin in the output plane
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int cp = it * 16 + (lane >> 2);
-        const int hp = cp + 1;
-        co_ok[it] = cp >= 1 && cp <= PAIR_TW;
-        co_lds[it] = hp * 4 + co_k;
-        co_goff[it] = (unsigned)((cp * p.out_cstride + (co_k ^ halo_swz(hp)) * 8) * 2);
-    }
-    auto emit = [&](int w0, uint4* xa, int oy, int ox, T* plane, bool zero_outside, auto interior_tag) {
-        constexpr bool INTERIOR = decltype(interior_tag)::value;
-#pragma unroll
-        for (int row = 0; row < RPW; ++row) {
-            const int cr = RPW * wave + row;  // row inside the compute region
-            const int gy = oy + cr;
-#pragma unroll
-            for (int ph = 0; ph < 2; ++ph) {
-                const int cp = 16 * ph + q;   // pixel inside the compute region
-                const int gx = ox + cp;
-                const bool zero = !INTERIOR && zero_outside && !((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W);
-#pragma unroll
-                for (int wl2 = 0; wl2 < 2; ++wl2) {
-                    const f32x4 v = w0 ? acc[row][2 + wl2][ph] : acc[row][wl2][ph];
-                    f32x4 o = lrelu4(v);
-                    if (!INTERIOR && zero) o = f32x4{0.f, 0.f, 0.f, 0.f};
-                    // channels 16*wl2 + 4*sl + j: slot 2*wl2 + (sl >> 1), bytes 8*(sl & 1)..
-                    const int hp = cp + 1;
-                    char* dst = reinterpret_cast<char*>(xa + ((cr + 1) * HALO_W + hp) * 4 + ((2 * wl2 + (sl >> 1)) ^ halo_swz(hp))) +
-                                8 * (sl & 1);
-                    *reinterpret_cast<uint2*>(dst) = Op<T>::pack4(o[0], o[1], o[2], o[3]);
-                }
-            }
-        }
-        FW_STAMP(6);  // emit: convert + LDS writes
-        // copy-out: logical slot = physical ^ swizzle(px).  All LDS reads first (unconditional: they stay inside the tile),
-        // then the stores.
-        uint4 cv[RPW][2];
+    // ---- emit: accumulators -> LeakyReLU -> typed, without a transpose through LDS and BEFORE the barrier ------------------
+    // A lane's D fragments hold channels 4*sl.. of tile w0 and of tile w0+1 for pixel 16*ph + q (8 B each).  One
+    // v_permlane16_swap per dword (rows of 16 lanes: odd rows of the first operand <-> even rows of the second) leaves every
+    // lane with 16 contiguous bytes: lanes with even sl get channels 4*sl..4*sl+7 of tile w0 (their own 8 B + those of lane
+    // ^ 16), lanes with odd sl channels 4*(sl-1)..+7 of tile w0+1.  That is one whole 8-channel slot of the pixel:
+    //     ls = sl even ? sl / 2 : 2 + sl / 2
+    // so the global store is 16 B per lane / 64 contiguous bytes per pixel straight from registers, and x_a goes into its LDS
+    // tile with one ds_write_b128 per fragment.  Everything up to the LDS write needs no barrier: a wave converts and stores
+    // as soon as ITS last item is done - the older wave of a SIMD while the younger one still runs MFMAs, the younger one
+    // with the VALU to itself (with the convert behind the barrier both waves of a SIMD converted at the same time: 18 % of
+    // the kernel, phase stamps in DESIGN.md section 6).
+    const int ls = (sl & 1) ? 2 + (sl >> 1) : (sl >> 1);
+    const unsigned st_off = (unsigned)((q * p.out_cstride + ls * 8) * 2);  // store offset from (row, compute-region px 16*ph)
+    auto convert = [&](int w0, uint4 (&pk)[RPW][2]) {
 #pragma unroll
         for (int row = 0; row < RPW; ++row)
 #pragma unroll
-            for (int it = 0; it < 2; ++it) cv[row][it] = xa[(RPW * wave + row + 1) * (HALO_W * 4) + co_lds[it]];
+            for (int ph = 0; ph < 2; ++ph) {
+                const f32x4 va = lrelu4(w0 ? acc[row][2][ph] : acc[row][0][ph]);
+                const f32x4 vb = lrelu4(w0 ? acc[row][3][ph] : acc[row][1][ph]);
+                const uint2 pa = Op<T>::pack4(va[0], va[1], va[2], va[3]);
+                const uint2 pb = Op<T>::pack4(vb[0], vb[1], vb[2], vb[3]);
+                const u32x2 sx = __builtin_amdgcn_permlane16_swap(pa.x, pb.x, false, false);
+                const u32x2 sy = __builtin_amdgcn_permlane16_swap(pa.y, pb.y, false, false);
+                pk[row][ph] = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            }
+    };
+    // valid interior of the compute region -> global plane (pixels 0 / 31 and rows 0 / 15 are the recompute ring)
+    auto store_out = [&](const uint4 (&pk)[RPW][2], int oy, int ox, T* plane, auto interior_tag) {
+        constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
         for (int row = 0; row < RPW; ++row) {
             const int cr = RPW * wave + row;
@@ -213,10 +191,25 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_kern
             if (!row_ok) continue;
             char* rowbase = reinterpret_cast<char*>(plane) + ((long)gy * p.W + ox) * p.out_cstride * 2;  // wave-uniform
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int gx = ox + it * 16 + (lane >> 2);
-                if (co_ok[it] && (INTERIOR || (unsigned)gx < (unsigned)p.W))
-                    *reinterpret_cast<uint4*>(rowbase + co_goff[it]) = cv[row][it];
+            for (int ph = 0; ph < 2; ++ph) {
+                const int cp = 16 * ph + q;
+                if (cp >= 1 && cp <= PAIR_TW && (INTERIOR || (unsigned)(ox + cp) < (unsigned)p.W))
+                    *reinterpret_cast<uint4*>(rowbase + (long)(16 * ph) * p.out_cstride * 2 + st_off) = pk[row][ph];
+            }
+        }
+    };
+    // x_a -> its halo-format tile in LDS (zero outside the image = conv_b's zero padding; border tiles only)
+    auto write_xa = [&](const uint4 (&pk)[RPW][2], uint4* xa, int oy, int ox, auto interior_tag) {
+        constexpr bool INTERIOR = decltype(interior_tag)::value;
+#pragma unroll
+        for (int row = 0; row < RPW; ++row) {
+            const int cr = RPW * wave + row;
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                const int cp = 16 * ph + q, hp = cp + 1;
+                uint4 v = pk[row][ph];
+                if (!INTERIOR && !((unsigned)(oy + cr) < (unsigned)p.H && (unsigned)(ox + cp) < (unsigned)p.W)) v = make_uint4(0, 0, 0, 0);
+                xa[((cr + 1) * HALO_W + hp) * 4 + (ls ^ halo_swz(hp))] = v;
             }
         }
     };
@@ -296,36 +289,45 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_kern
             wait_dma = true;
         }
         FW_STAMP(1);
-        // conv_a done.  Every wave must be finished with the last chunk's stage before it becomes the x_a tile.
-        // In flight: the x_a item's weights and the next tile's first chunk, both issued an item ago.
+        // conv_a done for this wave.  In flight: the x_a item's weights and the next tile's first chunk, both issued an item
+        // ago - waited for ahead of the stores (vmcnt counts stores too).
         if (!(FW_PAIR_DBG & 32)) FW_WAIT_VMCNT(0);
         FW_STAMP(5);
-        __syncthreads();
-        FW_STAMP(0);
         // the whole 16x32 compute region inside the image?  (uniform; false only for border tiles)
         const bool interior = oy >= 0 && ox >= 0 && oy + TILE_H <= p.H && ox + TILE_W <= p.W;
+        uint4 pk[RPW][2];
         if (!(FW_PAIR_DBG & 4)) {
+            convert(0, pk);
             if (interior)
-                emit(0, lds + ((qd - 1) & 1) * ACT_REGION, oy, ox, reinterpret_cast<T*>(p.out_a), true, std::true_type{});
+                store_out(pk, oy, ox, reinterpret_cast<T*>(p.out_a), std::true_type{});
             else
-                emit(0, lds + ((qd - 1) & 1) * ACT_REGION, oy, ox, reinterpret_cast<T*>(p.out_a), true, std::false_type{});
+                store_out(pk, oy, ox, reinterpret_cast<T*>(p.out_a), std::false_type{});
         }
-        FW_STAMP(3);  // emit of x_a
-        run_item(na, std::false_type{}, false);
-        FW_STAMP(2);  // x_a item compute
-        // conv_b done: every wave has finished reading the x_a tile before it is reused as the store-transpose buffer.
-        // In flight: the x_a stores (an item old) and the next tile's first weights.
-        if (!(FW_PAIR_DBG & 32)) FW_WAIT_VMCNT(0);
-        FW_STAMP(5);
+        FW_STAMP(6);  // emit: convert + stores
+        // every wave must be finished with the last chunk's stage before it becomes the x_a tile
         __syncthreads();
         FW_STAMP(0);
         if (!(FW_PAIR_DBG & 4)) {
             if (interior)
-                emit(2, lds + ((qd - 1) & 1) * ACT_REGION, oy, ox, reinterpret_cast<T*>(p.out_b), false, std::true_type{});
+                write_xa(pk, lds + ((qd - 1) & 1) * ACT_REGION, oy, ox, std::true_type{});
             else
-                emit(2, lds + ((qd - 1) & 1) * ACT_REGION, oy, ox, reinterpret_cast<T*>(p.out_b), false, std::false_type{});
+                write_xa(pk, lds + ((qd - 1) & 1) * ACT_REGION, oy, ox, std::false_type{});
         }
-        FW_STAMP(3);
+        FW_STAMP(3);  // x_a tile into LDS
+        run_item(na, std::false_type{}, false);
+        FW_STAMP(2);  // x_a item compute
+        // conv_b done for this wave.  In flight: the x_a stores (an item old) and the next tile's first weights.  No barrier:
+        // the x_a tile's stage is refilled only behind the next item's barrier.
+        if (!(FW_PAIR_DBG & 32)) FW_WAIT_VMCNT(0);
+        FW_STAMP(5);
+        if (!(FW_PAIR_DBG & 4)) {
+            convert(2, pk);
+            if (interior)
+                store_out(pk, oy, ox, reinterpret_cast<T*>(p.out_b), std::true_type{});
+            else
+                store_out(pk, oy, ox, reinterpret_cast<T*>(p.out_b), std::false_type{});
+        }
+        FW_STAMP(6);
     }
     FW_STAMP_FLUSH(p.stamps);
 }
