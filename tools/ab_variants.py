@@ -50,8 +50,10 @@ def main():
         name, _, flags = spec.partition("=")
         name, _, sd = name.partition(":")
         srcdir = (ROOT / sd) if sd else B.CSRC
-        rebuild(srcdir, flags.split())
-        r = subprocess.run([sys.executable, "-c", CHILD % str(ROOT)], capture_output=True, text=True)
+        toks = flags.split()
+        env = dict(os.environ, **dict(t[4:].split("=", 1) for t in toks if t.startswith("ENV:")))  # ENV:NAME=VALUE tokens
+        rebuild(srcdir, [t for t in toks if not t.startswith("ENV:")])
+        r = subprocess.run([sys.executable, "-c", CHILD % str(ROOT)], capture_output=True, text=True, env=env)
         line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:]
         print(f"{name:24s} {line}", flush=True)
     rebuild(B.CSRC, [])

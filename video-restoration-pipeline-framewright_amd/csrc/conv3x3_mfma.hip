@@ -50,7 +50,8 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
     const int qn = NB >> 3, rn = NB & 7;
     const int lb = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blockIdx.x >> 3);
     const int tiles_x = (p.W + TILE_W - 1) / TILE_W;
-    const int ntiles = tiles_x * ((p.H + TILE_H - 1) / TILE_H);
+    const int tiles_y = (p.H + TILE_H - 1) / TILE_H;
+    const int ntiles = tiles_x * tiles_y;
     const int t_lo = (int)((long)lb * ntiles / NB);
     const int t_hi = (int)((long)(lb + 1) * ntiles / NB);
     if (t_lo >= t_hi) return;
@@ -96,7 +97,9 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
     const char* a_src = nullptr;   // uniform: halo origin of (tile a_t, chunk a_c)
     int a_n = 0, a_t = t_lo, a_c = 0;
     auto plan_tile = [&]() {
-        const int ty0 = (a_t / tiles_x) * TILE_H, tx0 = (a_t % tiles_x) * TILE_W;
+        int aty, atx;
+        tile_pos(a_t, tiles_x, tiles_y, &aty, &atx);
+        const int ty0 = aty * TILE_H, tx0 = atx * TILE_W;
         const int sy0 = ups ? (ty0 >> 1) : ty0;
         const int sx0 = ups ? (tx0 >> 1) : tx0;
         a_src = in + ((long)(sy0 - 1) * Ws + (sx0 - 1)) * p.in_cstride * 2;
@@ -202,8 +205,10 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
     constexpr int dbg = FW_CONV_DEBUG;
     int n = 0;
     for (int t = t_lo; t < t_hi; ++t) {
-        const int y0 = (t / tiles_x) * TILE_H;
-        const int x0 = (t % tiles_x) * TILE_W;
+        int tty, ttx;
+        tile_pos(t, tiles_x, tiles_y, &tty, &ttx);
+        const int y0 = tty * TILE_H;
+        const int x0 = ttx * TILE_W;
         // accumulators start at the bias (re-read per tile: <= 256 B from L1/L2, cheaper than live registers)
 #pragma unroll
         for (int w = 0; w < NW; ++w) {

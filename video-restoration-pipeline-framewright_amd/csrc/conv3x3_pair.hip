@@ -53,7 +53,8 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_kern
     const int qn = NB >> 3, rn = NB & 7;
     const int lb = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blockIdx.x >> 3);
     const int tiles_x = (p.W + PAIR_TW - 1) / PAIR_TW;
-    const int ntiles = tiles_x * ((p.H + PAIR_TH - 1) / PAIR_TH);
+    const int tiles_y = (p.H + PAIR_TH - 1) / PAIR_TH;
+    const int ntiles = tiles_x * tiles_y;
     const int t_lo = (int)((long)lb * ntiles / NB);
     const int t_hi = (int)((long)(lb + 1) * ntiles / NB);
     if (t_lo >= t_hi) return;
@@ -87,8 +88,10 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_kern
 
     // compute-region origin of tile t (may be -1: the region starts one pixel outside the tile's valid outputs)
     auto origin = [&](int t, int* oy, int* ox) {
-        *oy = (t / tiles_x) * PAIR_TH - 1;
-        *ox = (t % tiles_x) * PAIR_TW - 1;
+        int ty, tx;
+        tile_pos(t, tiles_x, tiles_y, &ty, &tx);
+        *oy = ty * PAIR_TH - 1;
+        *ox = tx * PAIR_TW - 1;
     };
 
     // activation fetch stream: per tile the chunks 0..na-1, each fetched once, as one batch of ACT_ITERS pieces per wave.

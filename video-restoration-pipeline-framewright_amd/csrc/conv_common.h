@@ -84,6 +84,23 @@ constexpr int W_FRAGS = 18;                               // 9 taps x 2 k-steps 
 // Lanes whose halo position is outside the image read a 16-byte zero page instead, so every wave issues the same
 // number of DMA instructions per stage (the counted s_waitcnt vmcnt below relies on it) and zero padding costs
 // nothing.
+// Tile walk.  A workgroup owns a contiguous range of the linear tile index; FW_TILE_ORDER says how that index maps to the
+// grid: 0 = row-major (a workgroup walks a horizontal run), 1 = column-major (a vertical run: a tile shares 4 of its 18
+// halo rows with the tile the same workgroup did just before, and its left / right neighbours are being done at the same
+// time by workgroups of the same XCD).
+#ifndef FW_TILE_ORDER
+#define FW_TILE_ORDER 1
+#endif
+__device__ __forceinline__ void tile_pos(int t, int tiles_x, int tiles_y, int* ty, int* tx) {
+    if (FW_TILE_ORDER == 0) {
+        *ty = t / tiles_x;
+        *tx = t - *ty * tiles_x;
+    } else {
+        *tx = t / tiles_y;
+        *ty = t - *tx * tiles_y;
+    }
+}
+
 __host__ __device__ constexpr int halo_swz(int px) { return ((px >> 2) & 1) << 1; }
 
 template <int CT>

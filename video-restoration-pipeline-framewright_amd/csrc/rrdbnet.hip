@@ -50,6 +50,7 @@ struct fw_rrdbnet {
     ConvLayer conv_first, conv_body, conv_up1, conv_up2, conv_hr, conv_last;
     std::vector<ConvLayer> body;  // [num_block][3][5]
     Workspace ws;
+    int fuse_mask = 3;       // bit 0: conv1+conv2, bit 1: conv3+conv4 (FW_RRDB_FUSE_MASK, for A/B runs)
     bool fuse_pairs = true;  // conv1+conv2 / conv3+conv4 in one kernel (FW_RRDB_FUSE_PAIRS=0 disables, for A/B runs)
     // residual trunk as typed hi + typed lo planes (EPI_RESIDUAL_SPLIT): the residual adds run on the matrix cores as
     // identity chunks and conv5's epilogue loads nothing (FW_RRDB_SPLIT_TRUNK=0 selects the fp32 trunk, for A/B runs)
@@ -269,8 +270,8 @@ void forward(fw_rrdbnet* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, f
             const ConvLayer* L = &n->body[((size_t)b * 3 + k) * 5];
             // conv1..conv4: growth channels, LeakyReLU(0.2), written into the next plane    (:184-187);
             // fused in pairs (conv1+conv2, conv3+conv4): the shared input chunks leave HBM once per pair
-            if (n->fuse_pairs) {
-                for (int c = 0; c < 4; c += 2) {
+            for (int c = 0; c < 4; c += 2) {
+                if (n->fuse_pairs && (n->fuse_mask >> (c >> 1) & 1)) {
                     ConvPairParams q{};
                     q.in = cat[cur];
                     q.in_cstride = 32;
@@ -286,14 +287,14 @@ void forward(fw_rrdbnet* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, f
                     q.out_b = plane(cat[cur], 3 + c, PL);
                     q.out_cstride = 32;
                     run_pair(n, L[c], L[c + 1], q, st);
-                }
-            } else {
-                for (int c = 0; c < 4; ++c) {
-                    ConvParams p = base;
-                    p.in = cat[cur];
-                    p.out = plane(cat[cur], 2 + c, PL);
-                    p.act = 1;
-                    run_conv(n, L[c], EPI_STORE, p, st);
+                } else {
+                    for (int cc = c; cc < c + 2; ++cc) {
+                        ConvParams p = base;
+                        p.in = cat[cur];
+                        p.out = plane(cat[cur], 2 + cc, PL);
+                        p.act = 1;
+                        run_conv(n, L[cc], EPI_STORE, p, st);
+                    }
                 }
             }
             // conv5 + residual(s): x5*0.2 + x  (:188-189); after rdb3 additionally *0.2 + rrdb_in (:204)
@@ -431,6 +432,7 @@ int fw_rrdbnet_create(int device_id, int num_block, int scale, int dtype, fw_rrd
         n->dt = (DType)dtype;
         n->body.resize((size_t)num_block * 15);
         if (const char* e = getenv("FW_RRDB_FUSE_PAIRS")) n->fuse_pairs = atoi(e) != 0;
+        if (const char* e = getenv("FW_RRDB_FUSE_MASK")) n->fuse_mask = atoi(e) & 3;
         if (const char* e = getenv("FW_RRDB_SPLIT_TRUNK")) n->split_trunk = atoi(e) != 0;
         *out = n.release();
     });
