@@ -216,6 +216,14 @@ int fw_temporal_average_u8(const uint8_t* const* frames, const float* weights, i
 int fw_strength_blend_u8(const uint8_t* original, const uint8_t* denoised, double strength, size_t nbytes, uint8_t* out,
                          void* stream);
 
+/* cv2.resize(output, (int(w*outscale), int(h*outscale)), interpolation=cv2.INTER_LANCZOS4) on an 8-bit H x W x C image
+ * (C <= 4; device pointers): the last step of realesrgan.RealESRGANer.enhance when outscale != netscale — reference call
+ * site src/framewright/processors/pytorch_realesrgan.py:223 (`upsampler.enhance(img, outscale=config.scale_factor)`,
+ * scale_factor 2 with a x4 model).  OpenCV's fixed-point arithmetic (8x8 taps, 11-bit coefficients, clamped borders);
+ * synchronises `stream` before it returns. */
+int fw_resize_lanczos4_u8(const uint8_t* src, int src_h, int src_w, int channels, uint8_t* dst, int dst_h, int dst_w,
+                          void* stream);
+
 /* -------------------------------------------------------------------------------------------------
  * Restormer building blocks (the reference's DEFAULT TAP model)
  * replaces  `Restormer(dim=48, num_blocks=[4,6,6,8], num_refinement_blocks=4, heads=[1,2,4,8],

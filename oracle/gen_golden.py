@@ -338,9 +338,37 @@ def interfaces() -> None:
     print("wrote tests/golden/interfaces.json;", len(out), "classes;", "not importable:", failed)
 
 
+def assign_frames_logic() -> None:
+    """Fixture set 6 - `MultiGPUDistributor._assign_frames` (utils/multi_gpu.py:780-870) evaluated by the reference itself for
+    every LoadBalanceStrategy on synthetic GPUInfo lists.  -> tests/golden/assign_frames.json"""
+    import json
+    mg = load_reference("framewright.utils.multi_gpu")
+    rng = np.random.default_rng(77)
+    cases = []
+    for n_gpu in (1, 2, 3, 8):
+        for n_frames in (0, 1, 7, 40, 301):
+            for variant in range(3):
+                gpus = []
+                for i in range(n_gpu):
+                    total = int(rng.choice([24576, 81920, 294912]))
+                    free = 0 if variant == 2 else int(rng.integers(0, total + 1))
+                    util = 100.0 if variant == 2 else float(rng.integers(0, 101))
+                    gpus.append({"id": i if variant != 1 else (n_gpu - 1 - i) * 2, "name": f"g{i}", "total_vram_mb": total,
+                                 "free_vram_mb": free, "utilization_pct": util})
+                for strat in mg.LoadBalanceStrategy:
+                    d = mg.MultiGPUDistributor.__new__(mg.MultiGPUDistributor)
+                    d.strategy = strat
+                    plan = d._assign_frames(list(range(n_frames)), [mg.GPUInfo(**g) for g in gpus])
+                    cases.append({"gpus": gpus, "n_frames": n_frames, "strategy": strat.value,
+                                  "plan": {str(k): v for k, v in plan.items()}})
+    (ROOT / "tests" / "golden" / "assign_frames.json").write_text(json.dumps(cases))
+    print("wrote tests/golden/assign_frames.json;", len(cases), "cases")
+
+
 if __name__ == "__main__":
     main()
     host_logic()
     tap_logic()
     tile_and_flow_logic()
     interfaces()
+    assign_frames_logic()

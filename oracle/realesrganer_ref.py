@@ -82,9 +82,7 @@ def run_network(model: Model, img_rgb: np.ndarray, scale: int, tile: int = 0, ti
 def enhance(model: Model, img: np.ndarray, scale: int, outscale: Optional[float] = None, tile: int = 0,
             tile_pad: int = 10, pre_pad: int = 0) -> Tuple[np.ndarray, str]:
     """``RealESRGANer.enhance(img, outscale)`` for a cv2-style array (BGR / BGRA / gray, uint8 or uint16)."""
-    if outscale is not None and float(outscale) != float(scale):
-        raise NotImplementedError("outscale != netscale needs cv2.INTER_LANCZOS4; the reference never takes this "
-                                  "branch on the paths in scope (SURVEY.md §A.2)")
+    h_input, w_input = img.shape[:2]
     img = img.astype(np.float32)
     if np.max(img) > 256:
         max_range = 65535
@@ -117,6 +115,12 @@ def enhance(model: Model, img: np.ndarray, scale: int, outscale: Optional[float]
         res = (out_img * 65535.0).round().astype(np.uint16)
     else:
         res = (out_img * 255.0).round().astype(np.uint8)
+    if outscale is not None and float(outscale) != float(scale):
+        # cv2.resize(output, (int(w_input * outscale), int(h_input * outscale)), interpolation=cv2.INTER_LANCZOS4)
+        if res.dtype != np.uint8:
+            raise NotImplementedError("Lanczos resize of 16-bit output is not restated")
+        from .lanczos_ref import resize_lanczos4_u8
+        res = resize_lanczos4_u8(res, int(w_input * outscale), int(h_input * outscale))
     return res, img_mode
 
 

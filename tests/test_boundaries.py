@@ -46,6 +46,8 @@ def test_plugin_metadata_and_contract():
     assert PL.TAPDenoisePlugin().get_temporal_radius() == 2 and PL.TAPDenoisePlugin().supports_batch()
     with pytest.raises(RuntimeError, match="GPU device string"):
         p.initialize("cpu")
+    r = PL.RIFEInterpolatePlugin()
+    assert PL.PluginCapability.INTERPOLATE in r.get_metadata().capabilities and r.get_temporal_radius() == 1 and r.supports_batch()
 
 
 def test_shard_process_fn_reports_errors_like_reference(tmp_path, hip_lib):
@@ -119,3 +121,22 @@ def test_rocm_compute_backend_runs_models(hip_lib, tmp_path, monkeypatch):
             b.run_inference("rife-v4.6", (f0, f1))
     assert not b.is_initialized
     R.clear_upsampler_cache()
+
+
+@pytest.mark.gpu
+def test_rife_plugin_matches_the_engine(hip_lib, monkeypatch):
+    import numpy as np
+    from framewright_amd import rife as RF
+    from framewright_amd.synth import synthetic_frames, synthetic_ifnet_state
+    monkeypatch.setenv("FRAMEWRIGHT_AMD_SYNTHETIC_WEIGHTS", "1")
+    frames = list(synthetic_frames(3, 64, 96, seed=11))
+    pl = PL.RIFEInterpolatePlugin()
+    pl.initialize("cuda:0", {"dtype": "f16"})
+    eng = RF.IFNetEngine("f16", 0)
+    eng.load_state_dict(synthetic_ifnet_state())
+    mid = pl.process_frame(frames[0], 0, {"next_frame": frames[1]})
+    assert np.array_equal(mid, eng.interpolate(frames[0], frames[1]))
+    assert np.array_equal(pl.process_frame(frames[2], 2), frames[2])          # end of the clip: the frame itself
+    seq = pl.process_batch(frames, 0)
+    assert len(seq) == 5 and np.array_equal(seq[1], mid) and np.array_equal(seq[2], frames[1])
+    pl.cleanup()

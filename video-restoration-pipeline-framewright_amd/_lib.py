@@ -33,7 +33,7 @@ EXPORTS = [
     "fw_u8_to_nhwc", "fw_pixel_shuffle_add_u8",
     "fw_layernorm_nhwc", "fw_pack_pointwise", "fw_pointwise_nhwc", "fw_dwconv3x3_nhwc", "fw_attn_workspace_floats",
     "fw_attn_matrix", "fw_attn_apply", "fw_attn_pack", "fw_pixel_shuffle2_f32", "fw_copy_channels_f32", "fw_f32_to_planar", "fw_tap_post_u8",
-    "fw_flow_accumulate_u8", "fw_flow_accumulate_finish_u8",
+    "fw_flow_accumulate_u8", "fw_flow_accumulate_finish_u8", "fw_resize_lanczos4_u8",
 ]
 
 
@@ -110,6 +110,8 @@ def _declare_tap(lib: C.CDLL) -> None:
     lib.fw_temporal_average_u8.argtypes = [C.POINTER(vp), C.POINTER(f32), i32, sz, vp, vp]
     lib.fw_strength_blend_u8.restype = i32
     lib.fw_strength_blend_u8.argtypes = [vp, vp, f64, sz, vp, vp]
+    lib.fw_resize_lanczos4_u8.restype = i32
+    lib.fw_resize_lanczos4_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp]
 
 
 def _declare_ifnet(lib: C.CDLL) -> None:

@@ -5,6 +5,9 @@
 // called from reference src/framewright/processors/pytorch_realesrgan.py:223: BGR->RGB, /255, HWC->CHW
 // (here NHWC), for the x2 model reflect mod-pad to an even size followed by pixel_unshuffle(2)
 // (basicsr RRDBNet.forward).
+#include <cmath>
+#include <cstring>
+#include <vector>
 #include "fw_internal.h"
 
 // The blend kernels below restate float32 numpy arithmetic bit for bit: a*b+c must round twice, so this translation
@@ -382,6 +385,122 @@ void launch_strength_blend(const uint8_t* orig, const uint8_t* den, float one_mi
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(strength_blend_kernel, dim3(blocks), dim3(256), 0, st, orig, den, one_minus_s, s, n, out);
     FW_HIP_CHECK(hipGetLastError());
+}
+
+// ---- cv2.resize(..., interpolation=cv2.INTER_LANCZOS4) on 8-bit images ---------------------------------------------
+// RealESRGANer.enhance's last step when outscale != netscale (pip realesrgan, call site reference
+// src/framewright/processors/pytorch_realesrgan.py:223 `upsampler.enhance(img, outscale=config.scale_factor)`): the uint8
+// output is resized to (int(w*outscale), int(h*outscale)).  OpenCV's 8-bit path is fixed point: 8 horizontal and 8 vertical
+// taps, coefficients = saturate_cast<short>(c * 2048) of the normalised float Lanczos-4 weights, source indices clamped to
+// the image, result = saturate_cast<uchar>((sum + 2^21) >> 22).  The horizontal sums stay exact ints, so one fused pass over
+// the 8x8 footprint equals OpenCV's two passes bit for bit.  Tables come from the host (double sin/cos as OpenCV computes
+// them; a device libm could differ in the last place).
+__global__ __launch_bounds__(256) void resize_lanczos4_u8_kernel(const uint8_t* __restrict__ src, int Hs, int Ws, int C,
+                                                                 uint8_t* __restrict__ dst, int Hd, int Wd,
+                                                                 const int* __restrict__ xofs, const short* __restrict__ ialpha,
+                                                                 const int* __restrict__ yofs, const short* __restrict__ ibeta) {
+    const long total = (long)Hd * Wd;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int dy = (int)(i / Wd), dx = (int)(i - (long)dy * Wd);
+        const int sx = xofs[dx], sy = yofs[dy];
+        int xs[8];
+        short a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int x = sx + j - 3;
+            x = x < 0 ? 0 : (x >= Ws ? Ws - 1 : x);
+            xs[j] = x * C;
+            a[j] = ialpha[dx * 8 + j];
+            b[j] = ibeta[dy * 8 + j];
+        }
+        for (int c = 0; c < C; ++c) {
+            int v = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int y = sy + k - 3;
+                y = y < 0 ? 0 : (y >= Hs ? Hs - 1 : y);
+                const uint8_t* row = src + (long)y * Ws * C + c;
+                int h = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) h += (int)row[xs[j]] * a[j];
+                v += h * b[k];
+            }
+            v = (v + (1 << 21)) >> 22;
+            dst[i * C + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+}
+
+// OpenCV interpolateLanczos4 (imgproc, resize.cpp): weights of the 8 taps at fractional position x
+static void lanczos4_coeffs(float x, float* coeffs) {
+    static const double s45 = 0.70710678118654752440084436210485;
+    static const double cs[][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+    if (x < 1.1920928955078125e-7f) {  // FLT_EPSILON
+        for (int i = 0; i < 8; i++) coeffs[i] = 0;
+        coeffs[3] = 1;
+        return;
+    }
+    float sum = 0;
+    const double y0 = -(x + 3) * 3.1415926535897932384626433832795 * 0.25, s0 = std::sin(y0), c0 = std::cos(y0);
+    for (int i = 0; i < 8; i++) {
+        const double y = -(x + 3 - i) * 3.1415926535897932384626433832795 * 0.25;
+        coeffs[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+        sum += coeffs[i];
+    }
+    sum = 1.f / sum;
+    for (int i = 0; i < 8; i++) coeffs[i] *= sum;
+}
+
+static void lanczos4_tables(int ssize, int dsize, std::vector<int>& ofs, std::vector<short>& coef) {
+    const double inv_scale = (double)dsize / ssize, scale = 1. / inv_scale;
+    ofs.resize(dsize);
+    coef.resize((size_t)dsize * 8);
+    for (int d = 0; d < dsize; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        const int s0 = (int)std::floor(f);
+        f -= s0;
+        ofs[d] = s0;
+        float cbuf[8];
+        lanczos4_coeffs(f, cbuf);
+        for (int k = 0; k < 8; ++k) {
+            // saturate_cast<short>(float): round to nearest even, clamp
+            const float v = cbuf[k] * 2048.f;
+            long r = std::lrintf(v);
+            coef[(size_t)d * 8 + k] = (short)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r));
+        }
+    }
+}
+
+void launch_resize_lanczos4_u8(const uint8_t* src, int Hs, int Ws, int C, uint8_t* dst, int Hd, int Wd, hipStream_t st) {
+    std::vector<int> xofs, yofs;
+    std::vector<short> ia, ib;
+    lanczos4_tables(Ws, Wd, xofs, ia);
+    lanczos4_tables(Hs, Hd, yofs, ib);
+    const size_t nx = (size_t)Wd, ny = (size_t)Hd;
+    // one device block: [xofs | yofs | ialpha | ibeta]
+    const size_t bytes = (nx + ny) * 4 + (nx + ny) * 16;
+    char* d = nullptr;
+    FW_HIP_CHECK(hipMalloc((void**)&d, bytes));
+    std::vector<char> h(bytes);
+    memcpy(h.data(), xofs.data(), nx * 4);
+    memcpy(h.data() + nx * 4, yofs.data(), ny * 4);
+    memcpy(h.data() + (nx + ny) * 4, ia.data(), nx * 16);
+    memcpy(h.data() + (nx + ny) * 4 + nx * 16, ib.data(), ny * 16);
+    hipError_t e = hipMemcpyAsync(d, h.data(), bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        const long total = (long)Hd * Wd;
+        const int blocks = (int)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
+        hipLaunchKernelGGL(resize_lanczos4_u8_kernel, dim3(blocks), dim3(256), 0, st, src, Hs, Ws, C, dst, Hd, Wd,
+                           reinterpret_cast<const int*>(d), reinterpret_cast<const short*>(d + (nx + ny) * 4),
+                           reinterpret_cast<const int*>(d + nx * 4), reinterpret_cast<const short*>(d + (nx + ny) * 4 + nx * 16));
+        e = hipGetLastError();
+    }
+    // the tables live in pageable host memory and a per-call device block: finish before both go away (this is the
+    // once-per-frame tail of a non-default configuration, not the hot path)
+    const hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    FW_HIP_CHECK(e);
+    FW_HIP_CHECK(e2);
 }
 
 }  // namespace fw

@@ -167,6 +167,8 @@ void launch_strength_blend(const uint8_t* orig, const uint8_t* den, float one_mi
 
 void launch_flow_accumulate(const uint8_t* frame, const float* fx, const float* fy, const float* wmap, double wscale,
                             const float* mag, float thr, int inverse, int H, int W, double* acc, double* wsum, hipStream_t st);
+// cv2.resize(INTER_LANCZOS4) on 8-bit H x W x C images (device pointers); synchronises the stream
+void launch_resize_lanczos4_u8(const uint8_t* src, int Hs, int Ws, int C, uint8_t* dst, int Hd, int Wd, hipStream_t st);
 void launch_flow_accumulate_finish(const double* acc, const double* wsum, long n, uint8_t* out, hipStream_t st);
 
 // thread-local message returned by fw_last_error()

@@ -509,6 +509,12 @@ int fw_strength_blend_u8(const uint8_t* original, const uint8_t* denoised, doubl
     return guarded([&] { launch_strength_blend(original, denoised, oms, sf, (long)nbytes, out, (hipStream_t)stream); });
 }
 
+int fw_resize_lanczos4_u8(const uint8_t* src, int src_h, int src_w, int channels, uint8_t* dst, int dst_h, int dst_w, void* stream) {
+    if (!src || !dst || src_h < 1 || src_w < 1 || dst_h < 1 || dst_w < 1 || channels < 1 || channels > 4)
+        return fail(FW_ERR_INVALID, "fw_resize_lanczos4_u8: bad argument");
+    return guarded([&] { launch_resize_lanczos4_u8(src, src_h, src_w, channels, dst, dst_h, dst_w, (hipStream_t)stream); });
+}
+
 int fw_nafnet_destroy(fw_nafnet* n) {
     if (!n) return FW_OK;
     int prev = -1;

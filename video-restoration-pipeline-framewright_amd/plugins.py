@@ -163,6 +163,11 @@ _TAP_META = PluginMetadata(name="tap_denoise_mi355x", version="0.1.0",
                            capabilities={PluginCapability.DENOISE}, supports_cpu=False, min_vram_mb=2000)
 
 
+_RIFE_META = PluginMetadata(name="rife_mi355x", version="0.1.0",
+                            description="RIFE v4.6 frame interpolation on MI355X (hand-written HIP kernels)",
+                            capabilities={PluginCapability.INTERPOLATE}, supports_cpu=False, min_vram_mb=2000)
+
+
 class RealESRGANPlugin(ProcessorPlugin):
     @classmethod
     def get_metadata(cls) -> PluginMetadata:
@@ -219,3 +224,34 @@ class TAPDenoisePlugin(ProcessorPlugin):
 
     def process_batch(self, frames, start_frame, context=None):
         return self._dn.denoise_clip(list(frames))
+
+
+class RIFEInterpolatePlugin(ProcessorPlugin):
+    """IFNet v4.6 behind the plugin surface (temporal radius 1).  A frame-in / frame-out
+    interface cannot change the frame count, so ``process_frame`` returns the frame half-way between ``frame`` and
+    ``context["next_frame"]`` (the frame itself at the end of the clip) and ``process_batch`` the x2 sequence
+    ``[f0, mid01, f1, ..., f_{n-1}]`` the reference's ``rife -n 2n`` pass produces (interpolation.py:628-650)."""
+
+    @classmethod
+    def get_metadata(cls) -> PluginMetadata:
+        return _RIFE_META
+
+    def _on_initialize(self) -> None:
+        from . import rife as RF
+        self._fi = RF.FrameInterpolator(model=self._settings.get("model", "rife-v4.6"), gpu_id=_gpu_id(self._device),
+                                        dtype=self._settings.get("dtype", "f16"))
+
+    def get_temporal_radius(self) -> int:
+        return 1
+
+    def supports_batch(self) -> bool:
+        return True
+
+    def process_frame(self, frame, frame_number, context=None):
+        nxt = (context or {}).get("next_frame")
+        if nxt is None:
+            return frame
+        return self._fi._get_engine().interpolate(frame, nxt)
+
+    def process_batch(self, frames, start_frame, context=None):
+        return self._fi.double(list(frames))

@@ -225,6 +225,22 @@ def _check_frame(frame: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(frame)
 
 
+def resize_lanczos4_u8(img: np.ndarray, dst_w: int, dst_h: int, device_id: int = 0) -> np.ndarray:
+    """``cv2.resize(img, (dst_w, dst_h), interpolation=cv2.INTER_LANCZOS4)`` for an 8-bit H x W [x C] array, on the GPU
+    (fw_resize_lanczos4_u8: OpenCV's fixed-point arithmetic; oracle/lanczos_ref.py is the CPU restatement)."""
+    import torch
+    if img.dtype != np.uint8 or img.ndim not in (2, 3) or dst_w < 1 or dst_h < 1:
+        raise ValueError("resize_lanczos4_u8: uint8 H x W [x C] image and a positive size expected")
+    c = 1 if img.ndim == 2 else img.shape[2]
+    with torch.cuda.device(device_id):
+        src = torch.from_numpy(np.ascontiguousarray(img)).cuda()
+        dst = torch.empty((dst_h, dst_w) if img.ndim == 2 else (dst_h, dst_w, c), dtype=torch.uint8, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.load().fw_resize_lanczos4_u8(C.c_void_p(src.data_ptr()), img.shape[0], img.shape[1], c,
+                                                     C.c_void_p(dst.data_ptr()), dst_h, dst_w, C.c_void_p(st)))
+        return dst.cpu().numpy()
+
+
 # ---------------------------------------------------------------------------------------------------
 # RealESRGANer-compatible object (what get_upsampler() returns in the reference)
 # ---------------------------------------------------------------------------------------------------
@@ -265,10 +281,16 @@ class HipRealESRGANer:
         return out
 
     def enhance(self, img: np.ndarray, outscale: Optional[float] = None, alpha_upsampler: str = "realesrgan"):
+        out, mode = self._enhance_netscale(img)
         if outscale is not None and float(outscale) != float(self.scale):
-            raise NotImplementedError(
-                "outscale != netscale (Lanczos resize) is not on the accelerated path; every entry of the reference's "
-                "model table uses outscale == netscale (pytorch_realesrgan.py:103-129,223)")
+            # RealESRGANer.enhance: cv2.resize(output, (int(w_input * outscale), int(h_input * outscale)), INTER_LANCZOS4)
+            # on the quantised output, whatever its channel count (reached with scale_factor 2 and a x4 model,
+            # pytorch_realesrgan.py:223)
+            h_in, w_in = img.shape[:2]
+            out = resize_lanczos4_u8(out, int(w_in * outscale), int(h_in * outscale), self.engine.device_id)
+        return out, mode
+
+    def _enhance_netscale(self, img: np.ndarray):
         if img.dtype == np.uint16 or (img.dtype != np.uint8 and float(np.max(img)) > 256):
             raise NotImplementedError("16-bit frames are not supported by the uint8 frame path")
         img = np.asarray(img)
