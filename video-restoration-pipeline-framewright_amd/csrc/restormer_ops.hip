@@ -68,56 +68,99 @@ __global__ __launch_bounds__(256) void layernorm_nhwc_kernel(const float* __rest
 
 // ---- depthwise 3x3, zero padding, typed [H][W][ldx] -> typed [H][W][ldo] -------------------------------------------------
 // mode 0: out[c] = dw(x)[c], c < C.   mode 1: out[c] = gelu(dw(x)[c]) * dw(x)[C/2 + c], c < C/2 (exact erf GELU).
-// wdw: fp32 [C][9].  C % 8 == 0.  Filters in LDS as [tap][C].
+// wdw: fp32 [C][9].  C % 8 == 0.
+// A thread owns 8 channels of a column of DW_ROWS output pixels: the DW_ROWS + 2 input rows x 3 pixels it needs are 16-byte
+// loads issued without a branch between them (addresses clamped into the image, the value masked to zero outside), each
+// feeds up to three output rows, and the 72 filter taps of the 8 channels sit in registers for the whole column (the first
+// version - one pixel per thread, nine loads each behind its own border test and wait, filters re-read from LDS per pixel -
+// ran at a tenth of the memory bound).
+constexpr int DW_ROWS = 4;
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void dwconv3x3_nhwc_kernel(const T* __restrict__ x, long ldx, int H, int W, int C,
+__global__ __launch_bounds__(256, 2) void dwconv3x3_nhwc_kernel(const T* __restrict__ x, long ldx, int H, int W, int C,
                                                              const float* __restrict__ wdw, T* out, long ldo) {
-    extern __shared__ __attribute__((aligned(16))) float dw_w[];
+    extern __shared__ __attribute__((aligned(16))) float dw_w[];  // filters as [tap][C]
     for (int i = threadIdx.x; i < 9 * C; i += 256) {
         const int ch = i / 9, tap = i - ch * 9;
         dw_w[tap * C + ch] = wdw[i];
     }
     __syncthreads();
     const int Co = MODE == 1 ? C / 2 : C;
-    const int groups = Co / 8;
-    const long total = (long)H * W * groups;
+    const unsigned groups = Co / 8;
     using V = typename V8<T>::t;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const long pix = idx / groups;
-        const int g = (int)(idx - pix * groups);
-        const int yy = (int)(pix / W), xx = (int)(pix - (long)yy * W);
-        float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned row_items = (unsigned)W * groups;
+    const int strips = (H + DW_ROWS - 1) / DW_ROWS;
+    for (int strip = blockIdx.y; strip < strips; strip += gridDim.y)
+        for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < row_items; idx += gridDim.x * blockDim.x) {
+            const int xx = (int)(idx / groups);
+            const int g = (int)(idx - (unsigned)xx * groups);
+            const int y0 = strip * DW_ROWS;
+            float res[DW_ROWS][8];
+#pragma unroll 1
+            for (int half = 0; half < (MODE == 1 ? 2 : 1); ++half) {
+                const int c0 = half * Co + g * 8;
+                float wr[9][8];  // [tap][channel]
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int sy = yy + dy;
-            if (sy < 0 || sy >= H) continue;
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int sx = xx + dx;
-                if (sx < 0 || sx >= W) continue;
-                const T* src = x + ((long)sy * W + sx) * ldx;
-                const int tap = (dy + 1) * 3 + (dx + 1);
-                const V f1 = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(src + g * 8));
-                const float* w1 = dw_w + tap * C + g * 8;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) a1[j] += (float)f1[j] * w1[j];
-                if (MODE == 1) {
-                    const V f2 = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(src + Co + g * 8));
-                    const float* w2 = dw_w + tap * C + Co + g * 8;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) a2[j] += (float)f2[j] * w2[j];
+                for (int t = 0; t < 9; ++t) {
+                    const float4 w0 = *reinterpret_cast<const float4*>(dw_w + t * C + c0);
+                    const float4 w1 = *reinterpret_cast<const float4*>(dw_w + t * C + c0 + 4);
+                    wr[t][0] = w0.x, wr[t][1] = w0.y, wr[t][2] = w0.z, wr[t][3] = w0.w;
+                    wr[t][4] = w1.x, wr[t][5] = w1.y, wr[t][6] = w1.z, wr[t][7] = w1.w;
                 }
+                float acc[DW_ROWS][8];
+#pragma unroll
+                for (int o = 0; o < DW_ROWS; ++o)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[o][j] = 0.f;
+#pragma unroll
+                for (int r = 0; r < DW_ROWS + 2; ++r) {
+                    const int sy = y0 + r - 1;
+                    const bool rok = sy >= 0 && sy < H;
+                    const int cy = sy < 0 ? 0 : (sy >= H ? H - 1 : sy);
+                    V f[3];
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int sx = xx + dx - 1;
+                        const int cx = sx < 0 ? 0 : (sx >= W ? W - 1 : sx);
+                        f[dx] = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(x + ((long)cy * W + cx) * ldx + c0));
+                    }
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int sx = xx + dx - 1;
+                        const float m = (rok && sx >= 0 && sx < W) ? 1.f : 0.f;
+                        float v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = (float)f[dx][j] * m;
+#pragma unroll
+                        for (int o = 0; o < DW_ROWS; ++o) {
+                            const int dy = r - o;  // input row r feeds output row o through tap row dy
+                            if (dy >= 0 && dy < 3) {
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) acc[o][j] += v[j] * wr[dy * 3 + dx][j];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = 0; o < DW_ROWS; ++o)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (MODE == 1 && half == 0)
+                            res[o][j] = 0.5f * acc[o][j] * (1.0f + erff(acc[o][j] * 0.70710678118654752f));
+                        else if (MODE == 1)
+                            res[o][j] *= acc[o][j];
+                        else
+                            res[o][j] = acc[o][j];
+                    }
+            }
+#pragma unroll
+            for (int o = 0; o < DW_ROWS; ++o) {
+                if (y0 + o >= H) continue;
+                V ov;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ov[j] = (T)res[o][j];
+                *reinterpret_cast<uint4*>(out + ((long)(y0 + o) * W + xx) * ldo + g * 8) = __builtin_bit_cast(uint4, ov);
             }
         }
-        V o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float r = a1[j];
-            if (MODE == 1) r = 0.5f * r * (1.0f + erff(r * 0.70710678118654752f)) * a2[j];
-            o[j] = (T)r;
-        }
-        *reinterpret_cast<uint4*>(out + pix * ldo + g * 8) = __builtin_bit_cast(uint4, o);
-    }
 }
 
 // ---- MDTA Gram matrices ---------------------------------------------------------------------------------------------------
@@ -145,11 +188,24 @@ __global__ __launch_bounds__(256) void attn_gram_kernel(const T* __restrict__ qk
     for (long cb = blockIdx.x; cb < chunks; cb += gridDim.x) {
         const long p0 = cb * GRAM_PX;
         __syncthreads();
-        for (int i = threadIdx.x; i < GRAM_PX * dim; i += 256) {
-            const int px = i / dim, c = i - px * dim;
-            const long p = p0 + px;
-            gq[i] = p < M ? (float)qkv[p * ld + c] : 0.f;
-            gk[i] = p < M ? (float)qkv[p * ld + k_off + c] : 0.f;
+        // staging: 16-byte loads of 8 channels (ld, k_off and dim are multiples of 8)
+        {
+            using V = typename V8<T>::t;
+            const int d8 = dim >> 3;
+            for (int i = threadIdx.x; i < GRAM_PX * d8; i += 256) {
+                const int px = i / d8, c = (i - px * d8) << 3;
+                const long p = p0 + px;
+                V vq, vk;
+                if (p < M) {
+                    vq = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(qkv + p * ld + c));
+                    vk = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(qkv + p * ld + k_off + c));
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    gq[px * dim + c + j] = p < M ? (float)vq[j] : 0.f;
+                    gk[px * dim + c + j] = p < M ? (float)vk[j] : 0.f;
+                }
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -421,6 +477,11 @@ int fw_dwconv3x3_nhwc(int dtype, const void* x, long ldx, int H, int W, int chan
         (mode != 0 && mode != 1) || (mode == 1 && (channels & 15)))
         return rfail(FW_ERR_INVALID, "fw_dwconv3x3_nhwc: bad argument");
     return rguard([&] {
+        const int co = mode == 1 ? channels / 2 : channels;
+        const int strips = (H + fw::DW_ROWS - 1) / fw::DW_ROWS;
+        const int bx = blocks_for((long)W * (co / 8), 1024);
+        const int by_cap = 4096 / bx > 0 ? 4096 / bx : 1;   // every block stages the filters in LDS first: give it several strips
+        const dim3 blocks(bx, strips < by_cap ? strips : by_cap);
         const size_t smem = (size_t)9 * channels * sizeof(float);
         static const bool attr = [] {
             const int cap = 9 * 4096 * (int)sizeof(float);
@@ -431,10 +492,8 @@ int fw_dwconv3x3_nhwc(int dtype, const void* x, long ldx, int H, int W, int chan
             return true;
         }();
         (void)attr;
-        const int co = mode == 1 ? channels / 2 : channels;
-        const int blocks = blocks_for((long)H * W * (co / 8), 2048);
         hipStream_t st = (hipStream_t)stream;
-#define FW_DW(T, MO) hipLaunchKernelGGL((dwconv3x3_nhwc_kernel<T, MO>), dim3(blocks), dim3(256), smem, st, (const T*)x, ldx, H, W, channels, weight, (T*)out, ldo)
+#define FW_DW(T, MO) hipLaunchKernelGGL((dwconv3x3_nhwc_kernel<T, MO>), blocks, dim3(256), smem, st, (const T*)x, ldx, H, W, channels, weight, (T*)out, ldo)
         if (dtype == FW_DTYPE_BF16) { if (mode) FW_DW(__bf16, 1); else FW_DW(__bf16, 0); }
         else { if (mode) FW_DW(_Float16, 1); else FW_DW(_Float16, 0); }
 #undef FW_DW
@@ -451,8 +510,8 @@ int fw_attn_matrix(int dtype, const void* qkv, long ld, long M, int k_off, int h
                    float* workspace, float* attn, void* stream) {
     const int dim = heads * ch;
     if (bad_dtype(dtype) || !qkv || !temperature || !workspace || !attn || M < 1 || heads < 1 || (ch != 48 && ch != 96) ||
-        dim > 512 || heads * (ch / 3) * (ch / 3) > 8 * 256)
-        return rfail(FW_ERR_INVALID, "fw_attn_matrix: bad argument");
+        dim > 512 || heads * (ch / 3) * (ch / 3) > 8 * 256 || (ld & 7) || (k_off & 7) || ((size_t)qkv & 15))
+        return rfail(FW_ERR_INVALID, "fw_attn_matrix: bad argument (16-byte aligned rows expected)");
     return rguard([&] {
         hipStream_t st = (hipStream_t)stream;
         const long chunks = (M + GRAM_PX - 1) / GRAM_PX;
