@@ -89,6 +89,12 @@ int fw_rrdbnet_finalize(fw_rrdbnet* net);
 int fw_rrdbnet_upscale_u8(fw_rrdbnet* net, const uint8_t* in_bgr, int in_loc, int height, int width,
                           uint8_t* out_bgr, int out_loc, float* out_rgb_f32, void* stream);
 
+/* The same for a 16-bit frame (uint16 BGR, range 65535): RealESRGANer.enhance takes this branch when the image maximum
+ * exceeds 256 (cv2.imread(IMREAD_UNCHANGED) of a 16-bit PNG, reference pytorch_realesrgan.py:200-227): /65535 on the way in,
+ * clamp(0,1) * 65535, round-half-even, uint16 on the way out. */
+int fw_rrdbnet_upscale_u16(fw_rrdbnet* net, const uint16_t* in_bgr, int in_loc, int height, int width,
+                           uint16_t* out_bgr, int out_loc, float* out_rgb_f32, void* stream);
+
 /* Bytes of device workspace the net needs for an H x W input (0 on invalid arguments). */
 size_t fw_rrdbnet_workspace_bytes(const fw_rrdbnet* net, int height, int width);
 
@@ -215,6 +221,14 @@ int fw_temporal_average_u8(const uint8_t* const* frames, const float* weights, i
  * reference's Python float: (1 - s) is formed in double, then both factors are rounded once to float32. */
 int fw_strength_blend_u8(const uint8_t* original, const uint8_t* denoised, double strength, size_t nbytes, uint8_t* out,
                          void* stream);
+
+/* preserve_grain (tap_denoise.py:621-632; motion-adaptive variant :1015-1023 with its own factor):
+ *   grain = cv2.subtract(gray(original), cv2.GaussianBlur(gray(original), (0, 0), 3))
+ *   out   = cv2.add(denoised, (GRAY2BGR(grain) * factor).astype(np.uint8))
+ * on uint8 BGR H x W x 3 device buffers; `scratch` = height*width uint16 of device memory.  OpenCV's 8-bit fixed-point
+ * arithmetic (BGR2GRAY 14-bit weights; 19-tap bit-exact Gaussian, BORDER_REFLECT_101; saturating subtract / add). */
+int fw_grain_addback_u8(const uint8_t* original, const uint8_t* denoised, int height, int width, double factor,
+                        uint16_t* scratch, uint8_t* out, void* stream);
 
 /* cv2.resize(output, (int(w*outscale), int(h*outscale)), interpolation=cv2.INTER_LANCZOS4) on an 8-bit H x W x C image
  * (C <= 4; device pointers): the last step of realesrgan.RealESRGANer.enhance when outscale != netscale — reference call

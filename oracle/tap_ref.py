@@ -104,3 +104,57 @@ def strength_blend(original: np.ndarray, denoised: np.ndarray, strength: float) 
     o = original.astype(np.float32)
     d = denoised.astype(np.float32)
     return (o * (1 - strength) + d * strength).astype(np.uint8)
+
+
+# ---- preserve_grain (tap_denoise.py:621-632, motion-adaptive :1015-1023) ------------------------------------------------
+# cv2 is absent: BGR2GRAY, GaussianBlur(sigma 3 -> ksize 19, the 8-bit bit-exact fixed-point path), subtract and add are
+# restated from OpenCV's published algorithms - unpinned.  Written as OpenCV runs it (separate passes), unlike the kernels.
+def gaussian_kernel_fixed_point(n: int = 19, sigma: float = 3.0, bits: int = 8):
+    """getGaussianKernelBitExact + getGaussianKernelFixedPoint_ED: integer taps that sum to 2**bits."""
+    import math
+    scale2x = -0.125 / (sigma * sigma)
+    vals = [math.exp(scale2x * (x * x)) for x in range(1 - n, 0, 2)]
+    total = 2 * sum(vals) + 1
+    res, err, acc = [0] * n, 0.0, 0
+    for i in range(n // 2):
+        adj = vals[i] / total * (1 << bits) + err
+        v0 = int(np.rint(adj))
+        err = adj - v0
+        res[i] = res[n - 1 - i] = v0
+        acc += v0
+    res[n // 2] = (1 << bits) - 2 * acc
+    return np.array(res, np.int64)
+
+
+def _reflect101(idx: np.ndarray, n: int) -> np.ndarray:
+    if n == 1:
+        return np.zeros_like(idx)
+    idx = np.abs(idx)
+    period = 2 * (n - 1)
+    idx = idx % period
+    return np.where(idx >= n, period - idx, idx)
+
+
+def bgr2gray_u8(img: np.ndarray) -> np.ndarray:
+    b, g, r = (img[:, :, c].astype(np.int64) for c in range(3))
+    return ((b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+
+
+def gaussian_blur_u8_sigma3(gray: np.ndarray) -> np.ndarray:
+    k = gaussian_kernel_fixed_point()
+    h, w = gray.shape
+    g = gray.astype(np.int64)
+    xs = _reflect101(np.arange(w)[:, None] + np.arange(19)[None, :] - 9, w)           # [w][19]
+    hb = (g[:, xs] * k[None, None, :]).sum(axis=2)                                      # 8.8 sums, exact
+    ys = _reflect101(np.arange(h)[:, None] + np.arange(19)[None, :] - 9, h)
+    vb = (hb[ys, :] * k[None, :, None]).sum(axis=1)                                     # [h][19][w] -> [h][w], 16.16
+    return np.minimum((vb + (1 << 15)) >> 16, 255).astype(np.uint8)
+
+
+def grain_addback(original: np.ndarray, denoised: np.ndarray, factor: float = 0.3) -> np.ndarray:
+    gray = bgr2gray_u8(original)
+    blurred = gaussian_blur_u8_sigma3(gray)
+    grain = np.maximum(gray.astype(np.int64) - blurred.astype(np.int64), 0).astype(np.uint8)      # cv2.subtract
+    grain_3ch = np.repeat(grain[:, :, None], 3, axis=2)
+    add = (grain_3ch * factor).astype(np.uint8)
+    return np.minimum(denoised.astype(np.int64) + add.astype(np.int64), 255).astype(np.uint8)       # cv2.add

@@ -329,3 +329,38 @@ def test_out_of_memory_is_reported_with_the_word_memory(hip_lib, tmp_path, monke
     small = synthetic_frames(1, 16, 16, seed=1)[0]
     assert eng.upscale(small).shape == (64, 64, 3)
     eng.close()
+
+
+@pytest.mark.parametrize("scale", [4, 2])
+def test_16bit_frames_follow_the_65535_branch(hip_lib, scale):
+    """RealESRGANer.enhance on a 16-bit image (max > 256): /65535 in, clamp * 65535 round -> uint16 out, RGB / gray / RGBA;
+    checked against the CPU oracle (oracle/realesrganer_ref.py takes the same branch)."""
+    from oracle import realesrganer_ref as oref
+    sd = synthetic_rrdbnet_state(2, scale, seed=21)
+    eng = R.RRDBNetEngine(2, scale, "f16")
+    eng.load_state_dict(sd)
+    model = oref.make_model({k: torch.from_numpy(v) for k, v in sd.items()}, 2, scale)
+    f8 = synthetic_frames(1, 37, 50, seed=13)[0]
+    rng = np.random.default_rng(5)
+    f16 = (f8.astype(np.uint16) << 8) | rng.integers(0, 256, f8.shape, dtype=np.uint16)      # uses all 16 bits
+    up = R.HipRealESRGANer(scale, eng)
+    out, mode = up.enhance(f16, outscale=scale)
+    want, wmode = oref.enhance(model, f16, scale, outscale=scale)
+    assert out.dtype == np.uint16 and mode == wmode == "RGB" and out.shape == want.shape == (37 * scale, 50 * scale, 3)
+    d = np.abs(out.astype(np.int64) - want.astype(np.int64))
+    assert d.max() <= 1.0e-3 * 65535, d.max()                   # 1e-3 on the [0,1] scale (f16 operands)
+    mse = float(np.mean(d.astype(np.float64) ** 2))
+    assert 10 * np.log10(65535.0 ** 2 / max(mse, 1e-12)) >= 60.0
+    # the same picture as 8-bit data differs from the 16-bit result only by the input quantisation
+    out8, _ = up.enhance(f8, outscale=scale)
+    assert out8.dtype == np.uint8 and np.abs(out8.astype(np.int64) - (out.astype(np.int64) + 128) // 257).max() <= 16
+    g16 = f16[:, :, 1]
+    og, mg = up.enhance(g16, outscale=scale)
+    wg, _ = oref.enhance(model, g16, scale, outscale=scale)
+    assert mg == "L" and og.dtype == np.uint16 and np.abs(og.astype(np.int64) - wg.astype(np.int64)).max() <= 1.0e-3 * 65535 + 1
+    rgba = np.concatenate([f16, f16[:, :, :1]], axis=2)
+    oa, ma = up.enhance(rgba, outscale=scale)
+    assert ma == "RGBA" and oa.shape[2] == 4 and oa.dtype == np.uint16 and np.array_equal(oa[:, :, :3], out)
+    with pytest.raises(NotImplementedError):
+        up.enhance(f16, outscale=scale / 2)
+    eng.close()

@@ -213,3 +213,47 @@ def test_tile_blend_matches_reference_run(hip_lib):
         got = d._denoise_frame_tiled_device(torch.from_numpy(np.ascontiguousarray(frame)).cuda())
         torch.cuda.synchronize()
         np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("h,w", [(48, 64), (37, 51), (5, 7), (1, 1), (12, 200)])
+@pytest.mark.parametrize("factor", [0.3, 0.12])
+def test_grain_addback_bit_exact(hip_lib, h, w, factor):
+    """preserve_grain (tap_denoise.py:621-632) on the device == the numpy restatement of OpenCV's 8-bit arithmetic."""
+    rng = np.random.default_rng(h * 1000 + w)
+    orig = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    den = np.clip(orig.astype(np.int64) + rng.integers(-20, 21, orig.shape), 0, 255).astype(np.uint8)
+    if h >= 5:
+        den[:2] = 250                                                               # exercises the saturating add
+    dn = T.TAPDenoiser(T.TAPDenoiseConfig(model="nafnet"), engine=object())
+    got = dn._grain_addback_device(torch.from_numpy(orig).cuda(), torch.from_numpy(den).cuda(), factor).cpu().numpy()
+    np.testing.assert_array_equal(got, tap_ref.grain_addback(orig, den, factor))
+
+
+def test_clip_driver_with_preserve_grain(hip_lib, tmp_path, monkeypatch):
+    """strength blend, then the grain of the ORIGINAL added back (reference order, :614-632); the motion-aware driver scales
+    the factor by adjusted / base strength (:1015-1023)."""
+    from PIL import Image
+    args = SMALL
+    eng = T.NAFNetEngine(dtype="f16", **args)
+    eng.load_state_dict(synthetic_nafnet_state(seed=11, **args))
+    frames = list(synthetic_frames(4, 40, 56, seed=6))
+    plain = T.TAPDenoiser(T.TAPDenoiseConfig(model="nafnet", temporal_window=3, strength=0.7, tile_size=0), engine=eng).denoise_clip(frames)
+    grain = T.TAPDenoiser(T.TAPDenoiseConfig(model="nafnet", temporal_window=3, strength=0.7, tile_size=0, preserve_grain=True),
+                          engine=eng).denoise_clip(frames)
+    for f, p, g in zip(frames, plain, grain):
+        np.testing.assert_array_equal(g, tap_ref.grain_addback(f, p, 0.3))
+    eng.close()
+    monkeypatch.setenv("FRAMEWRIGHT_AMD_SYNTHETIC_WEIGHTS", "1")
+    src, dst = tmp_path / "in", tmp_path / "out"
+    src.mkdir()
+    for i, f in enumerate(frames[:2]):
+        Image.fromarray(f[:, :, ::-1]).save(src / f"frame_{i + 1:08d}.png")
+    tap = T.TAPDenoiseConfig(model="nafnet", tile_size=0, temporal_window=3, preserve_grain=True)
+    m = T.MotionAdaptiveTAPDenoiser(T.MotionAdaptiveConfig(base_strength=1.0, motion_sensitivity=1.0), tap, model_dir=tmp_path / "none")
+    res = m.denoise_frames_motion_aware(src, dst, [T.MotionLevel.STATIC, T.MotionLevel.EXTREME])
+    assert res.frames_processed == 2
+    outs = [np.asarray(Image.open(dst / f"frame_{i + 1:08d}.png"))[:, :, ::-1] for i in range(2)]
+    full = T.TAPDenoiser(T.TAPDenoiseConfig(model="nafnet", tile_size=0, temporal_window=3), model_dir=tmp_path / "none").denoise_clip(frames[:2])
+    np.testing.assert_array_equal(outs[0], tap_ref.grain_addback(frames[0], full[0], 0.3 * 1.0))
+    np.testing.assert_array_equal(outs[1], tap_ref.grain_addback(frames[1], tap_ref.strength_blend(frames[1], full[1], 0.4), 0.3 * 0.4))
+    m.clear_cache()

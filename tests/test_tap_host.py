@@ -146,3 +146,25 @@ def test_oracle_flow_accumulate_matches_reference_run():
                 flows.append(dict(flow_x=z, flow_y=z, magnitude=arrs[f"{k}_mag{i}"], confidence=arrs[f"{k}_conf{i}"]))
         np.testing.assert_array_equal(temporal_ref.denoise_with_flow(c["center"], window, flows, c["decay"]), arrs[k + "_out"])
         np.testing.assert_array_equal(temporal_ref.denoise_simple(frames, c["decay"]), arrs[k + "_simple"])
+
+
+def test_grain_oracle_known_answers():
+    """The numpy restatement of the preserve_grain arithmetic (OpenCV 8-bit paths; unpinned: cv2 is absent)."""
+    import numpy as np
+    from oracle import tap_ref
+    k = tap_ref.gaussian_kernel_fixed_point()
+    assert k.tolist() == [0, 1, 3, 4, 9, 14, 20, 28, 32, 34, 32, 28, 20, 14, 9, 4, 3, 1, 0] and int(k.sum()) == 256
+    flat = np.full((9, 13, 3), 77, np.uint8)
+    assert np.all(tap_ref.bgr2gray_u8(flat) == 77)                                    # the 14-bit weights sum to 2^14
+    assert np.all(tap_ref.gaussian_blur_u8_sigma3(tap_ref.bgr2gray_u8(flat)) == 77)  # taps sum to 256: constants survive
+    den = np.full_like(flat, 10)
+    assert np.array_equal(tap_ref.grain_addback(flat, den), den)                     # no high-pass content, nothing added
+    spike = flat.copy()
+    spike[4, 6] = 255
+    out = tap_ref.grain_addback(spike, den)
+    gray = tap_ref.bgr2gray_u8(spike)
+    blurred = tap_ref.gaussian_blur_u8_sigma3(gray)
+    # the spike: (255*34*34 + 77*(65536 - 34*34) + 2^15) >> 16 = 80 -> grain 175 -> int(175 * 0.3) = 52
+    assert int(blurred[4, 6]) == 80 and out[4, 6].tolist() == [62, 62, 62]
+    assert np.array_equal(out[0, 0], den[0, 0])                                      # away from the spike: blurred >= gray
+    assert tap_ref.bgr2gray_u8(np.array([[[255, 0, 0]]], np.uint8))[0, 0] == 29      # blue weight 1868 / 16384

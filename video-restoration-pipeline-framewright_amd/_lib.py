@@ -22,7 +22,7 @@ DTYPES = {"bf16": FW_DTYPE_BF16, "bfloat16": FW_DTYPE_BF16, "f16": FW_DTYPE_F16,
 # every symbol include/framewright_hip.h declares (tests/test_cabi.py checks the header against this list)
 EXPORTS = [
     "fw_last_error", "fw_abi_version", "fw_device_count",
-    "fw_rrdbnet_create", "fw_rrdbnet_set_conv", "fw_rrdbnet_finalize", "fw_rrdbnet_upscale_u8",
+    "fw_rrdbnet_create", "fw_rrdbnet_set_conv", "fw_rrdbnet_finalize", "fw_rrdbnet_upscale_u8", "fw_rrdbnet_upscale_u16",
     "fw_rrdbnet_workspace_bytes", "fw_rrdbnet_flops", "fw_rrdbnet_profile_enable", "fw_rrdbnet_profile_read",
     "fw_rrdbnet_destroy", "fw_pack_conv3x3", "fw_conv3x3_nhwc",
     "fw_nafnet_create", "fw_nafnet_set_tensor", "fw_nafnet_finalize", "fw_nafnet_denoise_u8", "fw_nafnet_flops",
@@ -33,7 +33,7 @@ EXPORTS = [
     "fw_u8_to_nhwc", "fw_pixel_shuffle_add_u8",
     "fw_layernorm_nhwc", "fw_pack_pointwise", "fw_pointwise_nhwc", "fw_dwconv3x3_nhwc", "fw_attn_workspace_floats",
     "fw_attn_matrix", "fw_attn_apply", "fw_attn_pack", "fw_pixel_shuffle2_f32", "fw_copy_channels_f32", "fw_f32_to_planar", "fw_tap_post_u8",
-    "fw_flow_accumulate_u8", "fw_flow_accumulate_finish_u8", "fw_resize_lanczos4_u8",
+    "fw_flow_accumulate_u8", "fw_flow_accumulate_finish_u8", "fw_resize_lanczos4_u8", "fw_grain_addback_u8",
 ]
 
 
@@ -69,6 +69,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.fw_rrdbnet_finalize.argtypes = [vp]
     lib.fw_rrdbnet_upscale_u8.restype = i32
     lib.fw_rrdbnet_upscale_u8.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp]
+    lib.fw_rrdbnet_upscale_u16.restype = i32
+    lib.fw_rrdbnet_upscale_u16.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp]
     lib.fw_rrdbnet_workspace_bytes.restype = sz
     lib.fw_rrdbnet_workspace_bytes.argtypes = [vp, i32, i32]
     lib.fw_rrdbnet_flops.restype = f64
@@ -110,6 +112,8 @@ def _declare_tap(lib: C.CDLL) -> None:
     lib.fw_temporal_average_u8.argtypes = [C.POINTER(vp), C.POINTER(f32), i32, sz, vp, vp]
     lib.fw_strength_blend_u8.restype = i32
     lib.fw_strength_blend_u8.argtypes = [vp, vp, f64, sz, vp, vp]
+    lib.fw_grain_addback_u8.restype = i32
+    lib.fw_grain_addback_u8.argtypes = [vp, vp, i32, i32, f64, vp, vp, vp]
     lib.fw_resize_lanczos4_u8.restype = i32
     lib.fw_resize_lanczos4_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp]
 

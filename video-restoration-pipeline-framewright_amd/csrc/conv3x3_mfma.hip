@@ -320,6 +320,12 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
                             o[1] = cg;
                             o[2] = cb;
                         }
+                        if (p.out_u16) {
+                            uint16_t* o = p.out_u16 + pix * 3;
+                            o[0] = (uint16_t)rintf(fminf(fmaxf(cb, 0.f), 1.f) * 65535.f);
+                            o[1] = (uint16_t)rintf(fminf(fmaxf(cg, 0.f), 1.f) * 65535.f);
+                            o[2] = (uint16_t)rintf(fminf(fmaxf(cr, 0.f), 1.f) * 65535.f);
+                        }
                         if (p.out_u8) {
                             uint8_t* o = p.out_u8 + pix * 3;
                             o[0] = (uint8_t)rintf(fminf(fmaxf(cb, 0.f), 1.f) * 255.f);

@@ -24,7 +24,11 @@ namespace fw {
 #define FW_PAIR_DBG 0
 #endif
 
+#ifdef FW_PAIR_TH_ABLATION  // timing-only ablation (wrong pixels on the ring): what a tile step of 16 rows would cost
+constexpr int PAIR_TH = FW_PAIR_TH_ABLATION;
+#else
 constexpr int PAIR_TH = TILE_H - 2;  // 14 valid rows per tile
+#endif
 constexpr int PAIR_TW = TILE_W - 2;  // 30 valid pixels per tile row
 
 struct PairSmem {

@@ -41,9 +41,11 @@ __device__ __forceinline__ int reflect_hi(int i, int n) { return i < n ? i : 2 *
 // UNSHUFFLE == 1: out[y][x][c] = in[y][x][2 - c] / 255 for c < 3, zero for 3 <= c < 32.
 // UNSHUFFLE == 2: out is ceil(H/2) x ceil(W/2); channel c*4 + dy*2 + dx = RGB channel c of input pixel
 //                 (2y+dy, 2x+dx) (torch.pixel_unshuffle order), zero for 12 <= ch < 32.
-template <typename T, int UNSHUFFLE>
-__global__ __launch_bounds__(256) void u8_to_nhwc_kernel(const uint8_t* __restrict__ in, int H, int W, T* out,
+// IN = uint8_t (/255) or uint16_t (/65535: RealESRGANer.enhance treats an image whose maximum exceeds 256 as 16-bit).
+template <typename T, int UNSHUFFLE, typename IN>
+__global__ __launch_bounds__(256) void u8_to_nhwc_kernel(const IN* __restrict__ in, int H, int W, T* out,
                                                          int out_cstride, int Ho, int Wo) {
+    constexpr float INV = sizeof(IN) == 1 ? 1.f / 255.f : 1.f / 65535.f;
     const long n = (long)Ho * Wo;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int y = (int)(i / Wo);
@@ -52,10 +54,10 @@ __global__ __launch_bounds__(256) void u8_to_nhwc_kernel(const uint8_t* __restri
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[k] = 0.f;
         if constexpr (UNSHUFFLE == 1) {
-            const uint8_t* px = in + ((size_t)y * W + x) * 3;
-            v[0] = px[2] * (1.f / 255.f);
-            v[1] = px[1] * (1.f / 255.f);
-            v[2] = px[0] * (1.f / 255.f);
+            const IN* px = in + ((size_t)y * W + x) * 3;
+            v[0] = px[2] * INV;
+            v[1] = px[1] * INV;
+            v[2] = px[0] * INV;
         } else {
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
@@ -63,9 +65,9 @@ __global__ __launch_bounds__(256) void u8_to_nhwc_kernel(const uint8_t* __restri
                 for (int dx = 0; dx < 2; ++dx) {
                     const int sy = reflect_hi(2 * y + dy, H);
                     const int sx = reflect_hi(2 * x + dx, W);
-                    const uint8_t* px = in + ((size_t)sy * W + sx) * 3;
+                    const IN* px = in + ((size_t)sy * W + sx) * 3;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) v[c * 4 + dy * 2 + dx] = px[2 - c] * (1.f / 255.f);
+                    for (int c = 0; c < 3; ++c) v[c * 4 + dy * 2 + dx] = px[2 - c] * INV;
                 }
         }
         uint4* o = reinterpret_cast<uint4*>(out + (size_t)i * out_cstride);
@@ -76,24 +78,35 @@ __global__ __launch_bounds__(256) void u8_to_nhwc_kernel(const uint8_t* __restri
     }
 }
 
-void launch_u8_to_nhwc(DType dt, const uint8_t* in_bgr, int H, int W, void* out, int out_cstride, int unshuffle,
-                       hipStream_t stream) {
+void launch_frame_to_nhwc(DType dt, const void* in_bgr, int bits, int H, int W, void* out, int out_cstride, int unshuffle,
+                          hipStream_t stream) {
     if (out_cstride < 32 || (out_cstride & 7)) throw Error(1, "u8_to_nhwc: bad channel stride");
+    if (bits != 8 && bits != 16) throw Error(1, "frame_to_nhwc: 8- or 16-bit samples expected");
     const int Ho = unshuffle == 2 ? (H + 1) / 2 : H;
     const int Wo = unshuffle == 2 ? (W + 1) / 2 : W;
     if (unshuffle == 2 && (H < 2 || W < 2)) throw Error(1, "u8_to_nhwc: x2 model needs at least 2x2 input");
     const long n = (long)Ho * Wo;
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     dim3 grid(blocks), block(256);
-#define FW_LAUNCH(T, U) \
-    hipLaunchKernelGGL((u8_to_nhwc_kernel<T, U>), grid, block, 0, stream, in_bgr, H, W, (T*)out, out_cstride, Ho, Wo)
-    if (dt == DT_BF16) {
-        if (unshuffle == 2) FW_LAUNCH(__bf16, 2); else FW_LAUNCH(__bf16, 1);
-    } else {
-        if (unshuffle == 2) FW_LAUNCH(_Float16, 2); else FW_LAUNCH(_Float16, 1);
-    }
+#define FW_LAUNCH(T, U, IN) \
+    hipLaunchKernelGGL((u8_to_nhwc_kernel<T, U, IN>), grid, block, 0, stream, (const IN*)in_bgr, H, W, (T*)out, out_cstride, Ho, Wo)
+#define FW_LAUNCH_T(T)                                                            \
+    do {                                                                          \
+        if (bits == 8) {                                                          \
+            if (unshuffle == 2) FW_LAUNCH(T, 2, uint8_t); else FW_LAUNCH(T, 1, uint8_t);    \
+        } else {                                                                  \
+            if (unshuffle == 2) FW_LAUNCH(T, 2, uint16_t); else FW_LAUNCH(T, 1, uint16_t);  \
+        }                                                                         \
+    } while (0)
+    if (dt == DT_BF16) FW_LAUNCH_T(__bf16); else FW_LAUNCH_T(_Float16);
+#undef FW_LAUNCH_T
 #undef FW_LAUNCH
     FW_HIP_CHECK(hipGetLastError());
+}
+
+void launch_u8_to_nhwc(DType dt, const uint8_t* in_bgr, int H, int W, void* out, int out_cstride, int unshuffle,
+                       hipStream_t stream) {
+    launch_frame_to_nhwc(dt, in_bgr, 8, H, W, out, out_cstride, unshuffle, stream);
 }
 
 
@@ -501,6 +514,88 @@ void launch_resize_lanczos4_u8(const uint8_t* src, int Hs, int Ws, int C, uint8_
     (void)hipFree(d);
     FW_HIP_CHECK(e);
     FW_HIP_CHECK(e2);
+}
+
+// ---- grain add-back (reference src/framewright/processors/tap_denoise.py:621-632, :1015-1023) -------------------------
+//   gray = cv2.cvtColor(orig, COLOR_BGR2GRAY); blurred = cv2.GaussianBlur(gray, (0, 0), 3); grain = cv2.subtract(gray, blurred)
+//   denoised = cv2.add(denoised, (GRAY2BGR(grain) * factor).astype(np.uint8))
+// restated from OpenCV's published 8-bit arithmetic (cv2 is absent here: unpinned): BGR2GRAY = (1868 B + 9617 G + 4899 R +
+// 2^13) >> 14; GaussianBlur of an 8-bit image with sigma 3 takes ksize 19 and the bit-exact fixed-point path - the float
+// kernel converted to 8 fraction bits with error diffusion so that it sums to 256 (grain_kernel19 below), horizontal sums
+// exact in 8.8, vertical sums exact in 16.16, result (sum + 2^15) >> 16, BORDER_REFLECT_101; subtract / add saturate; the
+// scaling is a float64 product truncated to uint8.
+struct GrainKernel {
+    int k[19];
+};
+
+__device__ __forceinline__ int gray_of(const uint8_t* px) { return (px[0] * 1868 + px[1] * 9617 + px[2] * 4899 + (1 << 13)) >> 14; }
+
+__global__ __launch_bounds__(256) void grain_hblur_kernel(const uint8_t* __restrict__ bgr, int H, int W, uint16_t* hbuf, GrainKernel gk) {
+    const long n = (long)H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W), x = (int)(i - (long)y * W);
+        int acc = 0;
+#pragma unroll
+        for (int j = 0; j < 19; ++j) acc += gk.k[j] * gray_of(bgr + ((long)y * W + reflect101(x + j - 9, W)) * 3);
+        hbuf[i] = (uint16_t)acc;   // <= 255 * 256
+    }
+}
+
+__global__ __launch_bounds__(256) void grain_add_kernel(const uint8_t* __restrict__ orig, const uint16_t* __restrict__ hbuf,
+                                                        const uint8_t* __restrict__ den, int H, int W, double factor,
+                                                        uint8_t* out, GrainKernel gk) {
+    const long n = (long)H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W), x = (int)(i - (long)y * W);
+        int acc = 0;
+#pragma unroll
+        for (int j = 0; j < 19; ++j) acc += gk.k[j] * (int)hbuf[(long)reflect101(y + j - 9, H) * W + x];
+        int blurred = (acc + (1 << 15)) >> 16;
+        blurred = blurred > 255 ? 255 : blurred;
+        int grain = gray_of(orig + i * 3) - blurred;
+        grain = grain < 0 ? 0 : grain;
+        const int add = (int)(uint8_t)(long)((double)grain * factor);   // float64 product, astype(uint8)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int v = den[i * 3 + c] + add;
+            out[i * 3 + c] = (uint8_t)(v > 255 ? 255 : v);
+        }
+    }
+}
+
+// getGaussianKernelBitExact(19, 3) + getGaussianKernelFixedPoint_ED(8 fraction bits)
+static GrainKernel grain_kernel19() {
+    constexpr int n = 19;
+    const double sigma = 3.0, scale2x = -0.125 / (sigma * sigma);
+    double v[n / 2], sum = 0;
+    for (int i = 0, x = 1 - n; i < n / 2; ++i, x += 2) {
+        v[i] = std::exp((double)(x * x) * scale2x);
+        sum += v[i];
+    }
+    sum = sum * 2 + 1;
+    const double mul = 1.0 / sum;
+    GrainKernel g;
+    double err = 0;
+    long tot = 0;
+    for (int i = 0; i < n / 2; ++i) {
+        const double adj = v[i] * mul * 256.0 + err;
+        const long v0 = std::lrint(adj);   // cvRound: to nearest even
+        err = adj - (double)v0;
+        g.k[i] = g.k[n - 1 - i] = (int)v0;
+        tot += v0;
+    }
+    g.k[n / 2] = (int)(256 - 2 * tot);
+    return g;
+}
+
+void launch_grain_addback(const uint8_t* orig, const uint8_t* den, int H, int W, double factor, uint16_t* tmp, uint8_t* out,
+                          hipStream_t st) {
+    static const GrainKernel gk = grain_kernel19();
+    const long n = (long)H * W;
+    const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(grain_hblur_kernel, dim3(blocks), dim3(256), 0, st, orig, H, W, tmp, gk);
+    hipLaunchKernelGGL(grain_add_kernel, dim3(blocks), dim3(256), 0, st, orig, tmp, den, H, W, factor, out, gk);
+    FW_HIP_CHECK(hipGetLastError());
 }
 
 }  // namespace fw

@@ -48,6 +48,7 @@ struct ConvParams {
     const float* res2;     // optional second residual
     float s1, s2;
     uint8_t* out_u8;       // EPI_IMAGE: HxWx3 BGR uint8 (optional)
+    uint16_t* out_u16;     // EPI_IMAGE: HxWx3 BGR uint16 = clamp -> x65535 -> rint (16-bit frames; optional)
     float* out_rgb;        // EPI_IMAGE: HxWx3 RGB float, un-clamped (optional)
     int img_H, img_W;      // EPI_IMAGE: size of the stored image (crop of the H x W conv output; mod-pad removal)
     int act;               // EPI_STORE: 1 = LeakyReLU(0.2), 2 = PReLU with per-output-channel slopes in chan_scale
@@ -106,6 +107,9 @@ size_t pack_conv3x3_weights(DType dt, const float* w, int cout, int cin, int cou
 // 2 = pixel_unshuffle(2) front end of the x2 model (12 channels), with reflect mod-padding to even size.
 void launch_u8_to_nhwc(DType dt, const uint8_t* in_bgr, int H, int W, void* out, int out_cstride,
                        int unshuffle, hipStream_t stream);
+// the same for 8- or 16-bit samples (bits; 16: uint16 BGR, /65535)
+void launch_frame_to_nhwc(DType dt, const void* in_bgr, int bits, int H, int W, void* out, int out_cstride, int unshuffle,
+                          hipStream_t stream);
 // SRVGGNetCompact tail: PixelShuffle(scale) of the last conv (fp32 [H][W][cstride], channel c*scale^2 + i*scale + j) plus
 // the nearest-upsampled input, -> RGB float and/or clamp -> x255 -> rint -> uint8 BGR, both [scale*H][scale*W][3].
 void launch_pixel_shuffle_add(const float* conv, int cstride, const uint8_t* in_bgr, int H, int W, int scale, uint8_t* out_bgr,
@@ -167,6 +171,9 @@ void launch_strength_blend(const uint8_t* orig, const uint8_t* den, float one_mi
 
 void launch_flow_accumulate(const uint8_t* frame, const float* fx, const float* fy, const float* wmap, double wscale,
                             const float* mag, float thr, int inverse, int H, int W, double* acc, double* wsum, hipStream_t st);
+// grain add-back of the TAP driver (tap_denoise.py:621-632); tmp: H*W uint16 scratch
+void launch_grain_addback(const uint8_t* orig, const uint8_t* den, int H, int W, double factor, uint16_t* tmp, uint8_t* out,
+                          hipStream_t st);
 // cv2.resize(INTER_LANCZOS4) on 8-bit H x W x C images (device pointers); synchronises the stream
 void launch_resize_lanczos4_u8(const uint8_t* src, int Hs, int Ws, int C, uint8_t* dst, int Hd, int Wd, hipStream_t st);
 void launch_flow_accumulate_finish(const double* acc, const double* wsum, long n, uint8_t* out, hipStream_t st);

@@ -509,6 +509,13 @@ int fw_strength_blend_u8(const uint8_t* original, const uint8_t* denoised, doubl
     return guarded([&] { launch_strength_blend(original, denoised, oms, sf, (long)nbytes, out, (hipStream_t)stream); });
 }
 
+int fw_grain_addback_u8(const uint8_t* original, const uint8_t* denoised, int height, int width, double factor,
+                        uint16_t* scratch, uint8_t* out, void* stream) {
+    if (!original || !denoised || !scratch || !out || height < 1 || width < 1 || !(factor >= 0.0) || factor > 1.0)
+        return fail(FW_ERR_INVALID, "fw_grain_addback_u8: bad argument");
+    return guarded([&] { launch_grain_addback(original, denoised, height, width, factor, scratch, out, (hipStream_t)stream); });
+}
+
 int fw_resize_lanczos4_u8(const uint8_t* src, int src_h, int src_w, int channels, uint8_t* dst, int dst_h, int dst_w, void* stream) {
     if (!src || !dst || src_h < 1 || src_w < 1 || dst_h < 1 || dst_w < 1 || channels < 1 || channels > 4)
         return fail(FW_ERR_INVALID, "fw_resize_lanczos4_u8: bad argument");

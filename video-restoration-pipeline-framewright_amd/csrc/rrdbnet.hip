@@ -125,8 +125,8 @@ Plan make_plan(const fw_rrdbnet* n, int H, int W) {
         o += align_up(bytes, 256);
         return at;
     };
-    p.in_u8 = take((size_t)H * W * 3);
-    p.out_u8 = take((size_t)H * W * 3 * s * s);
+    p.in_u8 = take((size_t)H * W * 3 * 2);            // staging of host frames: up to 16 bits per sample
+    p.out_u8 = take((size_t)H * W * 3 * s * s * 2);
     p.in32 = take(px * 32 * 2);
     // concat buffers: 6 planes of 32 channels (x, x1..x4); the split trunk adds planes 6-7 (lo part of x) and a third
     // buffer, which keeps the RRDB input alive until rdb3's second residual
@@ -219,7 +219,8 @@ void run_pair(fw_rrdbnet* n, const ConvLayer& a, const ConvLayer& b, const ConvP
     }
 }
 
-void forward(fw_rrdbnet* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, float* d_rgb, hipStream_t st) {
+// bits = 8: d_in / d_out are uint8 BGR; bits = 16: uint16 BGR (range 65535)
+void forward(fw_rrdbnet* n, const void* d_in, int bits, int H, int W, void* d_out, float* d_rgb, hipStream_t st) {
     int Ht, Wt;
     trunk_size(n, H, W, &Ht, &Wt);
     const Plan pl = make_plan(n, H, W);
@@ -236,7 +237,7 @@ void forward(fw_rrdbnet* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, f
     void* U2 = ws + pl.U2;
     void* U3 = ws + pl.U3;
 
-    launch_u8_to_nhwc(n->dt, d_in, H, W, in32, 32, n->scale == 2 ? 2 : 1, st);
+    launch_frame_to_nhwc(n->dt, d_in, bits, H, W, in32, 32, n->scale == 2 ? 2 : 1, st);
 
     // chunk-planar activations: a 192-channel concat buffer is 6 planes of [Ht][Wt][32]
     const long PL = (long)Ht * Wt * 32;
@@ -393,7 +394,10 @@ void forward(fw_rrdbnet* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, f
         p.W = 4 * Wt;
         p.in = U3;
         p.in_pstride = 16 * PL;
-        p.out_u8 = d_out;
+        if (bits == 16)
+            p.out_u16 = (uint16_t*)d_out;
+        else
+            p.out_u8 = (uint8_t*)d_out;
         p.out_rgb = d_rgb;
         p.img_H = n->scale * H;  // crops the mod-pad of the x2 model
         p.img_W = n->scale * W;
@@ -502,14 +506,15 @@ double fw_rrdbnet_flops(const fw_rrdbnet* n, int H, int W) {
     return 2.0 * mac * px;
 }
 
-int fw_rrdbnet_upscale_u8(fw_rrdbnet* n, const uint8_t* in_bgr, int in_loc, int H, int W, uint8_t* out_bgr,
-                          int out_loc, float* out_rgb_f32, void* stream) {
-    if (!n || !in_bgr) return fail(FW_ERR_INVALID, "fw_rrdbnet_upscale_u8: NULL argument");
-    if (!out_bgr && !out_rgb_f32) return fail(FW_ERR_INVALID, "fw_rrdbnet_upscale_u8: no output requested");
-    if (H < 1 || W < 1 || H > 16384 || W > 16384) return fail(FW_ERR_INVALID, "fw_rrdbnet_upscale_u8: bad frame size");
-    if (n->scale == 2 && (H < 2 || W < 2)) return fail(FW_ERR_INVALID, "fw_rrdbnet_upscale_u8: x2 needs >= 2x2 input");
+static int upscale_any(fw_rrdbnet* n, const void* in_bgr, int in_loc, int bits, int H, int W, void* out_bgr, int out_loc,
+                       float* out_rgb_f32, void* stream, const char* who) {
+    const std::string w(who);
+    if (!n || !in_bgr) return fail(FW_ERR_INVALID, w + ": NULL argument");
+    if (!out_bgr && !out_rgb_f32) return fail(FW_ERR_INVALID, w + ": no output requested");
+    if (H < 1 || W < 1 || H > 16384 || W > 16384) return fail(FW_ERR_INVALID, w + ": bad frame size");
+    if (n->scale == 2 && (H < 2 || W < 2)) return fail(FW_ERR_INVALID, w + ": x2 needs >= 2x2 input");
     if ((in_loc != FW_HOST && in_loc != FW_DEVICE) || (out_loc != FW_HOST && out_loc != FW_DEVICE))
-        return fail(FW_ERR_INVALID, "fw_rrdbnet_upscale_u8: bad buffer location");
+        return fail(FW_ERR_INVALID, w + ": bad buffer location");
     int rc = fw_rrdbnet_finalize(n);
     if (rc != FW_OK) return rc;
     return guarded([&] {
@@ -526,22 +531,32 @@ int fw_rrdbnet_upscale_u8(fw_rrdbnet* n, const uint8_t* in_bgr, int in_loc, int 
             FW_HIP_CHECK(hipMalloc((void**)&n->ws.base, pl.total));
             n->ws.bytes = pl.total;
         }
-        const size_t in_bytes = (size_t)H * W * 3;
+        const size_t in_bytes = (size_t)H * W * 3 * (bits / 8);
         const size_t out_bytes = in_bytes * n->scale * n->scale;
-        const uint8_t* d_in = in_bgr;
+        const void* d_in = in_bgr;
         if (in_loc == FW_HOST) {
-            uint8_t* stage = (uint8_t*)(n->ws.base + pl.in_u8);
+            void* stage = n->ws.base + pl.in_u8;
             FW_HIP_CHECK(hipMemcpyAsync(stage, in_bgr, in_bytes, hipMemcpyHostToDevice, st));
             d_in = stage;
         }
-        uint8_t* d_out = out_bgr;
-        if (out_bgr && out_loc == FW_HOST) d_out = (uint8_t*)(n->ws.base + pl.out_u8);
-        forward(n, d_in, H, W, d_out, out_rgb_f32, st);
+        void* d_out = out_bgr;
+        if (out_bgr && out_loc == FW_HOST) d_out = n->ws.base + pl.out_u8;
+        forward(n, d_in, bits, H, W, d_out, out_rgb_f32, st);
         if (out_bgr && out_loc == FW_HOST) {
             FW_HIP_CHECK(hipMemcpyAsync(out_bgr, d_out, out_bytes, hipMemcpyDeviceToHost, st));
             FW_HIP_CHECK(hipStreamSynchronize(st));
         }
     });
+}
+
+int fw_rrdbnet_upscale_u8(fw_rrdbnet* n, const uint8_t* in_bgr, int in_loc, int H, int W, uint8_t* out_bgr,
+                          int out_loc, float* out_rgb_f32, void* stream) {
+    return upscale_any(n, in_bgr, in_loc, 8, H, W, out_bgr, out_loc, out_rgb_f32, stream, "fw_rrdbnet_upscale_u8");
+}
+
+int fw_rrdbnet_upscale_u16(fw_rrdbnet* n, const uint16_t* in_bgr, int in_loc, int H, int W, uint16_t* out_bgr,
+                           int out_loc, float* out_rgb_f32, void* stream) {
+    return upscale_any(n, in_bgr, in_loc, 16, H, W, out_bgr, out_loc, out_rgb_f32, stream, "fw_rrdbnet_upscale_u16");
 }
 
 int fw_rrdbnet_profile_enable(fw_rrdbnet* n, int on) {

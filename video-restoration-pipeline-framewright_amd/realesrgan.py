@@ -85,7 +85,16 @@ class RRDBNetEngine:
 
     # -- inference ----------------------------------------------------------------------------------
     def upscale(self, frame_bgr: np.ndarray) -> np.ndarray:
-        """H x W x 3 uint8 BGR (host) -> sH x sW x 3 uint8 BGR (host)."""
+        """H x W x 3 uint8 BGR (host) -> sH x sW x 3 uint8 BGR (host); a uint16 frame (range 65535) comes back as uint16."""
+        if isinstance(frame_bgr, np.ndarray) and frame_bgr.dtype == np.uint16:
+            if frame_bgr.ndim != 3 or frame_bgr.shape[2] != 3:
+                raise ValueError("expected an H x W x 3 uint16 BGR frame")
+            f16 = np.ascontiguousarray(frame_bgr)
+            h, w = f16.shape[:2]
+            out16 = np.empty((h * self.scale, w * self.scale, 3), dtype=np.uint16)
+            _lib.check(self._lib.fw_rrdbnet_upscale_u16(self._h, _np_ptr(f16), _lib.FW_HOST, h, w, _np_ptr(out16),
+                                                        _lib.FW_HOST, None, None))
+            return out16
         frame_bgr = _check_frame(frame_bgr)
         h, w = frame_bgr.shape[:2]
         out = np.empty((h * self.scale, w * self.scale, 3), dtype=np.uint8)
@@ -263,7 +272,7 @@ class HipRealESRGANer:
             bgr = np.pad(bgr, ((0, self.pre_pad), (0, self.pre_pad), (0, 0)), mode="reflect")
         h, w = bgr.shape[:2]
         if self.tile_size > 0 and (h > self.tile_size or w > self.tile_size):
-            out = np.empty((h * s, w * s, 3), dtype=np.uint8)
+            out = np.empty((h * s, w * s, 3), dtype=bgr.dtype)
             t, pad = self.tile_size, self.tile_pad
             for ty in range(math.ceil(h / t)):
                 for tx in range(math.ceil(w / t)):
@@ -287,29 +296,40 @@ class HipRealESRGANer:
             # on the quantised output, whatever its channel count (reached with scale_factor 2 and a x4 model,
             # pytorch_realesrgan.py:223)
             h_in, w_in = img.shape[:2]
+            if out.dtype != np.uint8:
+                raise NotImplementedError("outscale != netscale on a 16-bit frame: OpenCV's float Lanczos path for ushort "
+                                          "images is not restated")
             out = resize_lanczos4_u8(out, int(w_in * outscale), int(h_in * outscale), self.engine.device_id)
         return out, mode
 
     def _enhance_netscale(self, img: np.ndarray):
-        if img.dtype == np.uint16 or (img.dtype != np.uint8 and float(np.max(img)) > 256):
-            raise NotImplementedError("16-bit frames are not supported by the uint8 frame path")
         img = np.asarray(img)
-        if img.dtype != np.uint8:
-            img = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+        # RealESRGANer.enhance: `if np.max(img) > 256: max_range = 65535` - a 16-bit image (cv2.imread(IMREAD_UNCHANGED) of a
+        # 16-bit PNG) is normalised by 65535 and comes back as uint16; anything else is 8-bit
+        sixteen = img.size > 0 and float(np.max(img)) > 256
+        if sixteen:
+            if not isinstance(self.engine, RRDBNetEngine):
+                raise NotImplementedError("16-bit frames are supported on the RRDBNet engines only (fw_rrdbnet_upscale_u16)")
+            img = img if img.dtype == np.uint16 else np.clip(np.rint(img), 0, 65535).astype(np.uint16)
+            top = 65535
+        else:
+            img = img if img.dtype == np.uint8 else np.clip(np.rint(img), 0, 255).astype(np.uint8)
+            top = 255
+
+        def gray_of(bgr_out):
+            # cv2.COLOR_BGR2GRAY weights, on the float image before quantisation in the reference; here on the quantised
+            # output (|diff| <= 1 LSB)
+            g = 0.114 * bgr_out[:, :, 0].astype(np.float32) + 0.587 * bgr_out[:, :, 1] + 0.299 * bgr_out[:, :, 2]
+            return np.clip(np.rint(g), 0, top).astype(img.dtype)
+
         with self._mu:
             if img.ndim == 2:
-                out = self._run_u8(np.repeat(img[:, :, None], 3, axis=2))
-                # cv2.COLOR_BGR2GRAY weights, on the float image before quantisation in the reference; here on
-                # the quantised output (|diff| <= 1 LSB)
-                g = 0.114 * out[:, :, 0].astype(np.float32) + 0.587 * out[:, :, 1] + 0.299 * out[:, :, 2]
-                return np.clip(np.rint(g), 0, 255).astype(np.uint8), "L"
+                return gray_of(self._run_u8(np.repeat(img[:, :, None], 3, axis=2))), "L"
             if img.shape[2] == 4:
                 out = self._run_u8(np.ascontiguousarray(img[:, :, :3]))
-                a = self._run_u8(np.repeat(img[:, :, 3:4], 3, axis=2))
-                ag = 0.114 * a[:, :, 0].astype(np.float32) + 0.587 * a[:, :, 1] + 0.299 * a[:, :, 2]
-                ag = np.clip(np.rint(ag), 0, 255).astype(np.uint8)
+                ag = gray_of(self._run_u8(np.repeat(img[:, :, 3:4], 3, axis=2)))
                 return np.concatenate([out, ag[:, :, None]], axis=2), "RGBA"
-            return self._run_u8(_check_frame(img)), "RGB"
+            return self._run_u8(img if sixteen else _check_frame(img)), "RGB"
 
 
 # ---------------------------------------------------------------------------------------------------

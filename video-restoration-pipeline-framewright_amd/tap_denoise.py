@@ -340,6 +340,17 @@ class TAPDenoiser:
                                                     C.c_void_p(out.data_ptr()), self._stream()))
         return out
 
+    def _grain_addback_device(self, original, denoised, factor: float = 0.3):
+        """preserve_grain (tap_denoise.py:621-632): high-pass of the original's gray image added back, on the device."""
+        import torch
+        h, w = int(original.shape[0]), int(original.shape[1])
+        out = torch.empty_like(original)
+        scratch = torch.empty((h, w), dtype=torch.int16, device=original.device)
+        _lib.check(_lib.load().fw_grain_addback_u8(C.c_void_p(original.data_ptr()), C.c_void_p(denoised.data_ptr()), h, w,
+                                                   float(factor), C.c_void_p(scratch.data_ptr()), C.c_void_p(out.data_ptr()),
+                                                   self._stream()))
+        return out
+
     # -- reference method names (numpy in / numpy out) -------------------------------------------------
     def _denoise_frame_tiled(self, frame: np.ndarray) -> np.ndarray:
         import torch
@@ -399,6 +410,8 @@ class TAPDenoiser:
                 d = self._temporal_average_device([den(j) for j in idx], [x / tot for x in ws])
             if self.config.strength < 1.0:
                 d = self._strength_blend_device(up(frames[i]), d)
+            if self.config.preserve_grain:
+                d = self._grain_addback_device(up(frames[i]), d)
             out.append(d)
             for j in [k for k in cache if k < i - half]:  # frames that no later window needs
                 del cache[j]
@@ -430,9 +443,6 @@ class TAPDenoiser:
         if not files:
             logger.warning(f"No frames found in {input_dir}")
             return result
-        if self.config.preserve_grain:
-            raise NotImplementedError("preserve_grain (cv2.GaussianBlur high-pass add-back, tap_denoise.py:621-632) is not on "
-                                      "the accelerated path")
         try:
             self._load_model()
         except Exception as e:  # noqa: BLE001 - reference contract: log and return the empty result
@@ -600,8 +610,6 @@ class MotionAdaptiveTAPDenoiser:
         if not den.is_available():
             logger.error("TAP denoising not available")
             return result
-        if self.tap_config.preserve_grain:
-            raise NotImplementedError("preserve_grain is not on the accelerated path")
         output_dir, input_dir = Path(output_dir), Path(input_dir)
         output_dir.mkdir(parents=True, exist_ok=True)
         result.output_dir = output_dir
@@ -622,10 +630,12 @@ class MotionAdaptiveTAPDenoiser:
         for f in files:
             img = _imread(f)
             frames.append(img[:, :, :3] if img is not None and img.ndim == 3 else None)
-        saved = den.config.strength
+        saved, saved_grain = den.config.strength, den.config.preserve_grain
+        want_grain = bool(self.tap_config.preserve_grain)   # (den.config may be the very same object)
         gains = []
         try:
             den.config.strength = 1.0                      # the window result un-blended, as _denoise_with_temporal_window returns it
+            den.config.preserve_grain = False              # grain goes in after the motion-adjusted blend, with its own factor
             outs = den.denoise_clip_device(frames)
             for i, f in enumerate(files):
                 if frames[i] is None or outs[i] is None:
@@ -634,10 +644,16 @@ class MotionAdaptiveTAPDenoiser:
                 else:
                     s = self.get_motion_adjusted_strength(levels[i])
                     d = outs[i]
+                    import torch
+                    orig_dev = None
                     if s < 1.0:
                         den.config.strength = s
-                        import torch
-                        d = den._strength_blend_device(torch.from_numpy(np.ascontiguousarray(frames[i])).to(d.device), d)
+                        orig_dev = torch.from_numpy(np.ascontiguousarray(frames[i])).to(d.device)
+                        d = den._strength_blend_device(orig_dev, d)
+                    if want_grain:                          # tap_denoise.py:1015-1023: less grain for high motion
+                        if orig_dev is None:
+                            orig_dev = torch.from_numpy(np.ascontiguousarray(frames[i])).to(d.device)
+                        d = den._grain_addback_device(orig_dev, d, 0.3 * (s / self.config.base_strength))
                     out = d.cpu().numpy()
                     _imwrite(output_dir / f.name, out)
                     result.frames_processed += 1
@@ -647,7 +663,7 @@ class MotionAdaptiveTAPDenoiser:
                 if progress_callback:
                     progress_callback((i + 1) / len(files))
         finally:
-            den.config.strength = saved
+            den.config.strength, den.config.preserve_grain = saved, saved_grain
         result.processing_time_seconds = time.time() - t0
         if gains:
             result.avg_psnr_improvement = float(np.mean(gains))
