@@ -339,6 +339,9 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_kern
     FW_STAMP_FLUSH(p.stamps);
 }
 
+bool pair_slide_enabled();
+void launch_conv3x3_pair_slide(DType dt, const ConvPairParams& p, int num_cus, hipStream_t stream);
+
 static int pair_num_cus() {
     static int n = [] {
         int dev = 0, v = 0;
@@ -361,6 +364,10 @@ void launch_conv3x3_pair(DType dt, const ConvPairParams& p_in, hipStream_t strea
 #ifdef FW_PAIR_STAMP
     p.stamps = stamp_buffer(0);
 #endif
+    if (pair_slide_enabled()) {  // the sliding-window form (conv3x3_pair_slide.hip); FW_PAIR_SLIDE=0 keeps the kernel below
+        launch_conv3x3_pair_slide(dt, p, pair_num_cus(), stream);
+        return;
+    }
     const int tiles = ((p.W + PAIR_TW - 1) / PAIR_TW) * ((p.H + PAIR_TH - 1) / PAIR_TH);
     dim3 grid(tiles < pair_num_cus() ? tiles : pair_num_cus()), block(64 * NWAVES);
     if (dt == DT_BF16)
