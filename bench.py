@@ -168,7 +168,7 @@ def main():
             "whole_path_tflops_per_gpu": flops_frame * args.steps / (dev_ms * 1e-3) / 1e12,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_note,
-                         "kernel": "conv3x3_mfma_kernel + conv3x3_pair_kernel (all instantiations)",
+                         "kernel": "conv3x3_mfma_kernel + conv3x3_pair_slide_kernel (all instantiations)",
                          "launches_timed": launches, "avg_launch_ms": conv_ms / max(launches, 1),
                          "avg_launch_gflop": conv_flops / max(launches, 1) / 1e9},
         }

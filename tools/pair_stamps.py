@@ -20,7 +20,7 @@ for k in (0, 1):
 for _ in range(3):
     eng.upscale_device(d, out=o)
 torch.cuda.synchronize()
-NAMES = [["barrier", "shared-item", "xa-item", "xa-lds-write", "tile-setup", "vmcnt", "convert+store"],
+NAMES = [["barrier", "shared-item", "xa-item", "xa-tile+carry", "tile-setup", "vmcnt", "convert+store"],
          ["barrier", "item", "residual-plane", "f32-epi", "tile-setup", "vmcnt", "typed-store"]]
 for k, (title, per_frame) in enumerate([("fused pair kernel", 138), ("64-channel residual conv (conv5, conv_body)", 70)]):
     lib.fw_debug_stamps(k, buf)

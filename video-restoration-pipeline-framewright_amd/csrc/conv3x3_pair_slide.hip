@@ -115,6 +115,7 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_slid
     const int lane = tid & 63;
     const int q = lane & 15;
     const int sl = lane >> 4;
+    FW_STAMP_INIT();  // phase stamps: diagnostic builds only (-DFW_PAIR_STAMP, conv_common.h)
 
     const int NB = gridDim.x;
     const int xcd = blockIdx.x & 7;
@@ -293,13 +294,17 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_slid
 #pragma unroll
                 for (int ph = 0; ph < 2; ++ph) acc[row][w][ph] = bv;
         }
+        FW_STAMP(4);  // tile set-up
         const int ipt = warm ? na : na + 1;
         // kind: 0 = shared chunk with both convs, 1 = shared chunk, conv_a only (warm-up), 2 = conv_b's x_a chunk
         auto run_item = [&](int j, auto kind_tag, bool wait_dma) {
             constexpr int KIND = decltype(kind_tag)::value;
             constexpr bool SHARED = KIND != 2;
+            FW_STAMP(SHARED ? 1 : 2);  // the previous phase ends
             if (wait_dma) FW_WAIT_VMCNT(0);
+            FW_STAMP(5);
             __syncthreads();
+            FW_STAMP(0);
             const bool more = n + 1 < nitems;
             const int jn = (j + 1 == ipt) ? 0 : j + 1;
             const bool fetch = SHARED && more && (j + 1 < na || t + 1 < t_hi);
@@ -340,8 +345,10 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_slid
                 run_item(j, std::integral_constant<int, 0>{}, wait_dma);
             wait_dma = true;
         }
+        FW_STAMP(1);
         // conv_a done for this wave; the DMAs in flight are an item old: wait ahead of the stores (vmcnt counts stores too)
         FW_WAIT_VMCNT(0);
+        FW_STAMP(5);
         // everything this tile reads, computes and stores inside the image?  (uniform)
         const bool interior = ox >= 0 && ox + TILE_W <= p.W && R0 >= 1 && R0 + TILE_H <= p.H;
         uint4 pk[RPW][2];
@@ -352,7 +359,9 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_slid
             else
                 store_out(pk, R0 + RPW * wave, ox, reinterpret_cast<T*>(p.out_a), std::false_type{});
         }
+        FW_STAMP(6);      // convert + stores of x_a
         __syncthreads();  // every wave is done with the last chunk's stage: it becomes the x_a tile
+        FW_STAMP(0);
         uint4* xa = lds + ((qd - 1) & 1) * PS_REGION;
         if (!warm || wave == NWAVES - 1) {
             if (interior)
@@ -366,9 +375,12 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_slid
                 const int i = wave * (PS_CARRY / NWAVES) + lane;
                 xa[i] = col_top ? make_uint4(0, 0, 0, 0) : carry[i];
             }
+            FW_STAMP(3);  // x_a tile (own rows + carry rows) into LDS
             run_item(na, std::integral_constant<int, 2>{}, false);
+            FW_STAMP(2);
         } else {
             __syncthreads();
+            FW_STAMP(0);
         }
         // rows 16, 17 of the x_a tile (wave 7's own conv_a rows: its LDS writes are ordered before these reads) -> carry, after
         // the barrier that ends every wave's reading of the old carry
@@ -379,16 +391,20 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_slid
                 if (i < PS_CARRY) carry[i] = xa[16 * ROW_PIECES + i];
             }
         }
+        FW_STAMP(3);  // carry rows
         if (!warm) {
             // conv_b done for this wave: rows R0 - 1 + (2w, 2w + 1).  In flight: the x_a stores (an item old), the next weights.
             FW_WAIT_VMCNT(0);
+            FW_STAMP(5);
             convert(2, pk);
             if (interior)
                 store_out(pk, R0 - 1 + RPW * wave, ox, reinterpret_cast<T*>(p.out_b), std::true_type{});
             else
                 store_out(pk, R0 - 1 + RPW * wave, ox, reinterpret_cast<T*>(p.out_b), std::false_type{});
+            FW_STAMP(6);  // convert + stores of x_b
         }
     }
+    FW_STAMP_FLUSH(p.stamps);
 }
 
 bool pair_slide_enabled() {
