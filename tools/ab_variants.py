@@ -37,8 +37,10 @@ print(json.dumps({"ms_per_frame": ms, "conv_tflops": conv_flops / conv_ms / 1e9,
 def rebuild(srcdir: Path, flags: list[str]) -> None:
     cc = B.hipcc()
     B.build()  # the other objects
-    for name in ("conv3x3_mfma", "conv3x3_pair"):
+    for name in ("conv3x3_mfma", "conv3x3_pair", "conv3x3_pair_slide"):
         src = srcdir / f"{name}.hip"
+        if not src.exists():
+            src = B.CSRC / f"{name}.hip"
         cmd = [cc, *flags, *B.CXXFLAGS, f"-I{B.INCLUDE}", f"-I{srcdir}", f"-I{B.CSRC}", "-c", str(src), "-o", str(B.OBJ_DIR / f"{name}.o")]
         subprocess.run(cmd, check=True)
     objs = [str(B.OBJ_DIR / (s.stem + ".o")) for s in B.sources()]

@@ -132,23 +132,31 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_slid
     const int na = p.na;
     const int nitems = (t_hi - t_lo) * (na + 1) + needs_warm * na;
 
-    // ---- per-lane DMA plan: 2560 pieces as five batched KiB per wave, pieces 2560..2583 as one more DMA of wave 0 ----------
-    unsigned relb[ACT_ITERS + 1];
-    auto piece_pos = [&](int i, int* row, int* px) {
-        const int idx = i < ACT_ITERS ? (ACT_ITERS * wave + i) * 64 + lane : ACT_ITERS * NWAVES * 64 + lane;
-        const int rw = idx / ROW_PIECES;
-        *px = (idx - rw * ROW_PIECES) >> 2;
-        *row = (idx < PS_PIECES) ? rw : -1;
-    };
-#pragma unroll
-    for (int i = 0; i <= ACT_ITERS; ++i) {
-        const int idx = i < ACT_ITERS ? (ACT_ITERS * wave + i) * 64 + lane : ACT_ITERS * NWAVES * 64 + lane;
+    // ---- per-lane DMA plan: 2560 pieces as five batched KiB per "virtual wave" v, pieces 2560..2583 as one more DMA of wave 0.
+    //      FW_DMA_OLD_ONLY: the older wave of every SIMD (waves 0-3) issues the batches of virtual waves 2w and 2w+1 and the
+    //      younger ones none: the younger wave is the critical path of every item, the older one waits at the barrier a
+    //      quarter of the time. -----------------------------------------------------------------------------------------------
+#ifndef FW_DMA_OLD_ONLY
+#define FW_DMA_OLD_ONLY 0
+#endif
+    constexpr int NBB = FW_DMA_OLD_ONLY ? 2 : 1;                       // batches per issuing wave
+    const bool issuer = FW_DMA_OLD_ONLY ? wave < NWAVES / 2 : true;    // wave-uniform
+    auto vwave = [&](int bt) { return FW_DMA_OLD_ONLY ? 2 * wave + bt : wave; };
+    auto piece_idx = [&](int bt, int i) { return i < ACT_ITERS ? (ACT_ITERS * vwave(bt) + i) * 64 + lane : ACT_ITERS * NWAVES * 64 + lane; };
+    unsigned relb[NBB][ACT_ITERS];
+    unsigned relb_x = 0;
+    auto piece_off = [&](int idx) {
         const int row = idx / ROW_PIECES;
         const int rm = idx - row * ROW_PIECES;
         const int px = rm >> 2;
         const int s = (rm & 3) ^ halo_swz(px);
-        relb[i] = (unsigned)(((row * p.W + px) * p.in_cstride + s * 8) * 2) + (i < ACT_ITERS ? (unsigned)(4 - i) * 1024u : 0u);
-    }
+        return (unsigned)(((row * p.W + px) * p.in_cstride + s * 8) * 2);
+    };
+#pragma unroll
+    for (int bt = 0; bt < NBB; ++bt)
+#pragma unroll
+        for (int i = 0; i < ACT_ITERS; ++i) relb[bt][i] = piece_off(piece_idx(bt, i)) + (unsigned)(4 - i) * 1024u;
+    relb_x = piece_off(piece_idx(0, ACT_ITERS));
     const bool extra_lane = wave == 0 && lane < PS_EXTRA;
     const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)lds;
     const char* in = reinterpret_cast<const char*>(p.in);
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_slid
         *ox = tx * PS_TW - 1;
     };
 
-    unsigned f_ok = 0;
+    unsigned f_ok = 0;            // bit bt * ACT_ITERS + i: piece i of batch bt is inside the image; bit 2 * ACT_ITERS: the extra piece
     bool f_all = true;
     const char* f_src = nullptr;  // halo origin (image row R0 - 2, column ox - 1) of (tile f_t, chunk f_c)
     int f_t = t_begin, f_c = 0;
@@ -173,32 +181,44 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_slid
         origin(f_t, &R0, &ox);
         f_src = in + ((long)(R0 - 2) * p.W + (ox - 1)) * p.in_cstride * 2;
         f_ok = 0;
+        auto inside = [&](int idx) {
+            const int row = idx / ROW_PIECES;
+            const int px = (idx - row * ROW_PIECES) >> 2;
+            return idx < PS_PIECES && (unsigned)(R0 - 2 + row) < (unsigned)p.H && (unsigned)(ox - 1 + px) < (unsigned)p.W;
+        };
 #pragma unroll
-        for (int i = 0; i <= ACT_ITERS; ++i) {
-            int row, px;
-            piece_pos(i, &row, &px);
-            const int gy = R0 - 2 + row;
-            const int gx = ox - 1 + px;
-            if (row >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) f_ok |= 1u << i;
-        }
+        for (int bt = 0; bt < NBB; ++bt)
+#pragma unroll
+            for (int i = 0; i < ACT_ITERS; ++i)
+                if (inside(piece_idx(bt, i))) f_ok |= 1u << (bt * ACT_ITERS + i);
+        if (inside(piece_idx(0, ACT_ITERS))) f_ok |= 1u << (2 * ACT_ITERS);
         // the extra piece only counts on the lanes that issue it
-        const unsigned need = extra_lane ? (2u << ACT_ITERS) - 1u : (1u << ACT_ITERS) - 1u;
+        const unsigned need = ((1u << (NBB * ACT_ITERS)) - 1u) | (extra_lane ? 1u << (2 * ACT_ITERS) : 0u);
         f_all = __builtin_amdgcn_readfirstlane(__all((f_ok & need) == need)) != 0;
     };
     auto issue_act = [&](int stage) {
         if (f_c == 0) plan_tile();
-        const unsigned dst = (unsigned)(stage * PS_REGION + ACT_ITERS * wave * 64);
-        const unsigned dst_x = lds_base + (unsigned)(stage * PS_REGION + ACT_ITERS * NWAVES * 64) * 16u;
-        if (f_all) {
-            glds16_batch_a(f_src, relb, lds_base + (dst + 4 * 64) * 16u);
-            if (extra_lane) glds16(f_src, relb[ACT_ITERS], dst_x);
-        } else {
+        if (issuer) {
+            const unsigned dst_x = lds_base + (unsigned)(stage * PS_REGION + ACT_ITERS * NWAVES * 64) * 16u;
 #pragma unroll
-            for (int i = 0; i < ACT_ITERS; ++i)
-                glds16_v(((f_ok >> i) & 1u) ? f_src + (relb[i] - (unsigned)(4 - i) * 1024u) : reinterpret_cast<const char*>(p.zeros),
-                         lds_base + (dst + i * 64) * 16u);
-            if (extra_lane)
-                glds16_v(((f_ok >> ACT_ITERS) & 1u) ? f_src + relb[ACT_ITERS] : reinterpret_cast<const char*>(p.zeros), dst_x);
+            for (int bt = 0; bt < NBB; ++bt) {
+                const unsigned dst = (unsigned)(stage * PS_REGION + ACT_ITERS * vwave(bt) * 64);
+                if (f_all) {
+                    glds16_batch_a(f_src, relb[bt], lds_base + (dst + 4 * 64) * 16u);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < ACT_ITERS; ++i)
+                        glds16_v(((f_ok >> (bt * ACT_ITERS + i)) & 1u) ? f_src + (relb[bt][i] - (unsigned)(4 - i) * 1024u)
+                                                                        : reinterpret_cast<const char*>(p.zeros),
+                                 lds_base + (dst + i * 64) * 16u);
+                }
+            }
+            if (extra_lane) {
+                if (f_all)
+                    glds16(f_src, relb_x, dst_x);
+                else
+                    glds16_v(((f_ok >> (2 * ACT_ITERS)) & 1u) ? f_src + relb_x : reinterpret_cast<const char*>(p.zeros), dst_x);
+            }
         }
         if (++f_c == na) {
             f_c = 0;
@@ -208,10 +228,15 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_slid
         }
     };
     auto issue_w = [&](int j, int ws) {
-        const int half = wave / (NWAVES / 2), k = wave % (NWAVES / 2);
-        if (half == 1 || j < na)
-            issue_w_half((half ? wb_b : wa_b) + (size_t)j * (W_FRAGS * 1024),
-                         lds_base + (unsigned)(SM::W_BASE + ws * SM::W_REGION + W_FRAGS * half * 64) * 16u, k, lane16);
+        if (!issuer) return;
+#pragma unroll
+        for (int bt = 0; bt < NBB; ++bt) {
+            const int v = vwave(bt);
+            const int half = v / (NWAVES / 2), k = v % (NWAVES / 2);
+            if (half == 1 || j < na)
+                issue_w_half((half ? wb_b : wa_b) + (size_t)j * (W_FRAGS * 1024),
+                             lds_base + (unsigned)(SM::W_BASE + ws * SM::W_REGION + W_FRAGS * half * 64) * 16u, k, lane16);
+        }
     };
 
     int rd_off[3][2];  // [dx][ph]: piece index of (halo row 2 * wave, px 16*ph + q + dx, slot sl)
