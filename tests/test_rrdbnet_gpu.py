@@ -364,3 +364,32 @@ def test_16bit_frames_follow_the_65535_branch(hip_lib, scale):
     with pytest.raises(NotImplementedError):
         up.enhance(f16, outscale=scale / 2)
     eng.close()
+
+
+def test_hipgraph_capture_gives_identical_frames(hip_lib, monkeypatch):
+    """FW_RRDB_GRAPH: the per-frame forward replayed from a captured hipGraph (small frames by default) == launched directly;
+    host and device buffers, a changed frame size and a re-used graph."""
+    import time
+    sd = synthetic_rrdbnet_state(3, 4, seed=8)
+    frames = synthetic_frames(3, 48, 64, seed=3)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FW_RRDB_GRAPH", mode)
+        eng = R.RRDBNetEngine(3, 4, "bf16")
+        eng.load_state_dict(sd)
+        res = [eng.upscale(f) for f in frames] + [eng.upscale(frames[0][:40, :52].copy())] + [eng.upscale(f) for f in frames[:2]]
+        d = torch.from_numpy(frames[1]).cuda()
+        o = torch.empty((192, 256, 3), dtype=torch.uint8, device="cuda")
+        for _ in range(3):
+            eng.upscale_device(d, out=o)
+        torch.cuda.synchronize()
+        res.append(o.cpu().numpy())
+        t0 = time.perf_counter()
+        for _ in range(20):
+            eng.upscale_device(d, out=o)
+        torch.cuda.synchronize()
+        outs[mode] = (res, (time.perf_counter() - t0) / 20 * 1e3)
+        eng.close()
+    for a, b in zip(outs["0"][0], outs["1"][0]):
+        assert np.array_equal(a, b)
+    print(f"48x64 x4, 3 blocks: direct {outs['0'][1]:.3f} ms, graph {outs['1'][1]:.3f} ms")

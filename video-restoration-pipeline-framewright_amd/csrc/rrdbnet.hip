@@ -55,6 +55,24 @@ struct fw_rrdbnet {
     // residual trunk as typed hi + typed lo planes (EPI_RESIDUAL_SPLIT): the residual adds run on the matrix cores as
     // identity chunks and conv5's epilogue loads nothing (FW_RRDB_SPLIT_TRUNK=0 selects the fp32 trunk, for A/B runs)
     bool split_trunk = true;
+    // hipGraph capture of the per-frame forward (BASELINE configs[4] "hipGraph-captured per-frame stages").  graph_mode: 0 never
+    // (default), 1 always, 2 for frames of at most graph_max_px input pixels.  Off by default because it buys nothing here: the
+    // launches of a forward run back to back at 1080p, and even a 48x64 frame through 3 blocks takes 0.61 ms either way (the
+    // persistent 256-workgroup kernels, not the launches, set the floor) - tests/test_rrdbnet_gpu.py prints both.  One executable
+    // graph per (frame size, sample bits, buffer pointers), rebuilt when the workspace moves.  FW_RRDB_GRAPH=0|1|2,
+    // FW_RRDB_GRAPH_MAX_PX.
+    int graph_mode = 0;
+    long graph_max_px = 512L * 512L;
+    struct GraphEntry {
+        int H, W, bits;
+        const void* in;
+        void* out;
+        float* rgb;
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+    };
+    std::vector<GraphEntry> graphs;
+    bool warmed = false;
     // profiling
     bool profile = false;
     std::vector<hipEvent_t> ev_pool;
@@ -437,6 +455,8 @@ int fw_rrdbnet_create(int device_id, int num_block, int scale, int dtype, fw_rrd
         n->body.resize((size_t)num_block * 15);
         if (const char* e = getenv("FW_RRDB_FUSE_PAIRS")) n->fuse_pairs = atoi(e) != 0;
         if (const char* e = getenv("FW_RRDB_FUSE_MASK")) n->fuse_mask = atoi(e) & 3;
+        if (const char* e = getenv("FW_RRDB_GRAPH")) n->graph_mode = atoi(e);
+        if (const char* e = getenv("FW_RRDB_GRAPH_MAX_PX")) n->graph_max_px = atol(e);
         if (const char* e = getenv("FW_RRDB_SPLIT_TRUNK")) n->split_trunk = atoi(e) != 0;
         *out = n.release();
     });
@@ -506,6 +526,14 @@ double fw_rrdbnet_flops(const fw_rrdbnet* n, int H, int W) {
     return 2.0 * mac * px;
 }
 
+static void drop_graphs(fw_rrdbnet* n) {
+    for (auto& g : n->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    n->graphs.clear();
+}
+
 static int upscale_any(fw_rrdbnet* n, const void* in_bgr, int in_loc, int bits, int H, int W, void* out_bgr, int out_loc,
                        float* out_rgb_f32, void* stream, const char* who) {
     const std::string w(who);
@@ -525,6 +553,7 @@ static int upscale_any(fw_rrdbnet* n, const void* in_bgr, int in_loc, int bits, 
         if (n->ws.bytes < pl.total) {
             // the previous workspace may still be in use by work queued on some stream
             FW_HIP_CHECK(hipDeviceSynchronize());
+            drop_graphs(n);   // they hold the old workspace's addresses
             if (n->ws.base) (void)hipFree(n->ws.base);
             n->ws.base = nullptr;
             n->ws.bytes = 0;
@@ -541,7 +570,48 @@ static int upscale_any(fw_rrdbnet* n, const void* in_bgr, int in_loc, int bits, 
         }
         void* d_out = out_bgr;
         if (out_bgr && out_loc == FW_HOST) d_out = n->ws.base + pl.out_u8;
-        forward(n, d_in, bits, H, W, d_out, out_rgb_f32, st);
+        // (the engine's first forward always runs uncaptured: one-time initialisations inside the launchers must not land in a
+        // capture)
+        const bool graphed = n->warmed && !n->profile &&
+                             (n->graph_mode == 1 || (n->graph_mode == 2 && (long)H * W <= n->graph_max_px));
+        n->warmed = true;
+        if (!graphed) {
+            forward(n, d_in, bits, H, W, d_out, out_rgb_f32, st);
+        } else {
+            fw_rrdbnet::GraphEntry* hit = nullptr;
+            for (auto& g : n->graphs)
+                if (g.H == H && g.W == W && g.bits == bits && g.in == d_in && g.out == d_out && g.rgb == out_rgb_f32) hit = &g;
+            if (!hit) {
+                if (n->graphs.size() >= 16) drop_graphs(n);   // callers that never reuse their buffers: do not grow without bound
+                (void)conv_zero_page();                       // its first use allocates: not inside a capture
+                // capture on a stream of our own: the caller's stream may be the legacy default stream, which cannot capture
+                hipStream_t cs = nullptr;
+                FW_HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+                fw_rrdbnet::GraphEntry e{H, W, bits, d_in, d_out, out_rgb_f32, nullptr, nullptr};
+                hipError_t err = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+                if (err == hipSuccess) {
+                    try {
+                        forward(n, d_in, bits, H, W, d_out, out_rgb_f32, cs);
+                    } catch (...) {
+                        hipGraph_t junk = nullptr;
+                        (void)hipStreamEndCapture(cs, &junk);
+                        if (junk) (void)hipGraphDestroy(junk);
+                        (void)hipStreamDestroy(cs);
+                        throw;
+                    }
+                    err = hipStreamEndCapture(cs, &e.graph);
+                }
+                if (err == hipSuccess) err = hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0);
+                (void)hipStreamDestroy(cs);
+                if (err != hipSuccess) {
+                    if (e.graph) (void)hipGraphDestroy(e.graph);
+                    FW_HIP_CHECK(err);
+                }
+                n->graphs.push_back(e);
+                hit = &n->graphs.back();
+            }
+            FW_HIP_CHECK(hipGraphLaunch(hit->exec, st));
+        }
         if (out_bgr && out_loc == FW_HOST) {
             FW_HIP_CHECK(hipMemcpyAsync(out_bgr, d_out, out_bytes, hipMemcpyDeviceToHost, st));
             FW_HIP_CHECK(hipStreamSynchronize(st));
@@ -601,6 +671,7 @@ int fw_rrdbnet_destroy(fw_rrdbnet* n) {
     free_layer(n->conv_up2);
     free_layer(n->conv_hr);
     free_layer(n->conv_last);
+    drop_graphs(n);
     if (n->ws.base) (void)hipFree(n->ws.base);
     for (auto e : n->ev_pool) (void)hipEventDestroy(e);
     if (prev >= 0) (void)hipSetDevice(prev);
