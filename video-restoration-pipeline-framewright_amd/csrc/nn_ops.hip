@@ -8,7 +8,7 @@
 // Data layout: the residual stream is fp32 NHWC ([pixel][C]); everything that feeds an MFMA is operand-typed NHWC.
 //   * pointwise_mfma_kernel : 1x1 conv / 2x2-s2 conv / 1x1+PixelShuffle as one MFMA GEMM D[cout][pixel], pixel on the
 //                             lane (same orientation as conv3x3_mfma.hip), fused SimpleGate / residual epilogues.
-//   * layernorm2d_kernel    : per-pixel LayerNorm over channels (HBM-bound, one wave per pixel, shuffles).
+//   * layernorm2d_kernel    : per-pixel LayerNorm over channels (HBM-bound, 16 / 32 / 64 lanes per pixel, shuffles).
 //   * dwconv3x3_gate_kernel : depthwise 3x3 + SimpleGate + per-channel partial sums for SCA (HBM-bound).
 //   * sca_kernel            : global-average-pool finish + 1x1 conv (a CxC mat-vec).
 #include "fw_internal.h"
@@ -309,26 +309,34 @@ size_t pack_pointwise_weights(DType dt, const float* w, int cout, int K, uint16_
 }
 
 // =====================================================================================================
-// LayerNorm2d over channels, fp32 in -> operand-typed out.  One wave per pixel; lane l holds channels
-// 4l..4l+3 (+256 per extra pass).  eps = 1e-6.
+// LayerNorm2d over channels, fp32 in -> operand-typed out.  LPP lanes per pixel (16 / 32 / 64 for C <= 64 / 128 / more), so
+// a wave normalises 64 / LPP pixels at once and every lane is busy at the narrow full-resolution levels (the first version
+// spent a whole wave on a pixel: at width 64, where four fifths of the LayerNorm bytes are, 48 of its 64 lanes idled).
+// Lane l of a pixel's group holds channels 4l..4l+3 (+256 per extra pass); the xor-shuffle tree over the group adds the
+// same terms in the same order as the 64-lane tree did with its idle lanes at zero.  eps = 1e-6.
 // =====================================================================================================
-template <typename T>
+template <typename T, int LPP>
 __global__ __launch_bounds__(256) void layernorm2d_kernel(const float* __restrict__ x, long M, int C, const float* w,
                                                           const float* b, T* out, float eps) {
+    constexpr int PPW = 64 / LPP;  // pixels per wave
     const int lane = threadIdx.x & 63;
+    const int sub = lane / LPP, cl = lane % LPP;
     const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
-    for (long m = wave0; m < M; m += nwaves) {
-        const float* row = x + m * C;
+    const long groups = (M + PPW - 1) / PPW;
+    for (long gi = wave0; gi < groups; gi += nwaves) {
+        const long m = gi * PPW + sub;
+        const bool live = m < M;
+        const float* row = x + (live ? m : 0) * C;
         float v[16];  // up to C = 1024
         float s = 0.f;
         const int passes = (C + 255) / 256;
 #pragma unroll
-        for (int pss = 0; pss < 4; ++pss) {
+        for (int pss = 0; pss < (LPP == 64 ? 4 : 1); ++pss) {
             if (pss < passes) {
-                const int c0 = pss * 256 + lane * 4;
+                const int c0 = pss * 256 + cl * 4;
                 f32x4 t = {0.f, 0.f, 0.f, 0.f};
-                if (c0 < C) t = *reinterpret_cast<const f32x4*>(row + c0);
+                if (c0 < C && live) t = *reinterpret_cast<const f32x4*>(row + c0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     v[pss * 4 + j] = t[j];
@@ -337,13 +345,13 @@ __global__ __launch_bounds__(256) void layernorm2d_kernel(const float* __restric
             }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        for (int o = LPP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
         const float mean = s / C;
         float q = 0.f;
 #pragma unroll
-        for (int pss = 0; pss < 4; ++pss) {
+        for (int pss = 0; pss < (LPP == 64 ? 4 : 1); ++pss) {
             if (pss < passes) {
-                const int c0 = pss * 256 + lane * 4;
+                const int c0 = pss * 256 + cl * 4;
                 if (c0 < C) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -354,13 +362,13 @@ __global__ __launch_bounds__(256) void layernorm2d_kernel(const float* __restric
             }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        for (int o = LPP / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
         const float rstd = 1.0f / sqrtf(q / C + eps);
 #pragma unroll
-        for (int pss = 0; pss < 4; ++pss) {
+        for (int pss = 0; pss < (LPP == 64 ? 4 : 1); ++pss) {
             if (pss < passes) {
-                const int c0 = pss * 256 + lane * 4;
-                if (c0 < C) {
+                const int c0 = pss * 256 + cl * 4;
+                if (c0 < C && live) {
                     float o4[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o4[j] = (v[pss * 4 + j] - mean) * rstd * w[c0 + j] + b[c0 + j];
@@ -374,13 +382,16 @@ __global__ __launch_bounds__(256) void layernorm2d_kernel(const float* __restric
 void launch_layernorm2d(DType dt, const float* x, long M, int C, const float* w, const float* b, void* out,
                         hipStream_t st) {
     if (C < 4 || (C & 3) || C > 1024) throw Error(1, "layernorm2d: C must be a multiple of 4, <= 1024");
-    const long blocks = (M + 3) / 4 < 4096 ? (M + 3) / 4 : 4096;
-    if (dt == DT_BF16)
-        hipLaunchKernelGGL((layernorm2d_kernel<__bf16>), dim3((unsigned)blocks), dim3(256), 0, st, x, M, C, w, b,
-                           (__bf16*)out, 1e-6f);
-    else
-        hipLaunchKernelGGL((layernorm2d_kernel<_Float16>), dim3((unsigned)blocks), dim3(256), 0, st, x, M, C, w, b,
-                           (_Float16*)out, 1e-6f);
+    const int lpp = C <= 64 ? 16 : (C <= 128 ? 32 : 64);
+    const long groups = (M + 64 / lpp - 1) / (64 / lpp);
+    const long blocks = (groups + 3) / 4 < 4096 ? (groups + 3) / 4 : 4096;
+#define FW_LN(T, L) hipLaunchKernelGGL((layernorm2d_kernel<T, L>), dim3((unsigned)blocks), dim3(256), 0, st, x, M, C, w, b, (T*)out, 1e-6f)
+    if (dt == DT_BF16) {
+        if (lpp == 16) FW_LN(__bf16, 16); else if (lpp == 32) FW_LN(__bf16, 32); else FW_LN(__bf16, 64);
+    } else {
+        if (lpp == 16) FW_LN(_Float16, 16); else if (lpp == 32) FW_LN(_Float16, 32); else FW_LN(_Float16, 64);
+    }
+#undef FW_LN
     FW_HIP_CHECK(hipGetLastError());
 }
 
