@@ -397,21 +397,23 @@ void launch_layernorm2d(DType dt, const float* x, long M, int C, const float* w,
 
 // =====================================================================================================
 // Depthwise 3x3 (zero pad 1) on a 2C-channel operand-typed NHWC tensor, fused SimpleGate (out[c] = dw[c] * dw[c+C]) and
-// per-channel partial sums of the gated output (for the SCA global average pool).  One thread = one pixel x 8
-// gated channels.
+// per-channel partial sums of the gated output (for the SCA global average pool).  One thread = 8 gated channels of a column
+// of GATE_ROWS output pixels.
 // =====================================================================================================
 constexpr int DW_MAX_BLOCKS = 1024;
+constexpr int GATE_ROWS = 3;
 
 template <typename T>
-__global__ __launch_bounds__(256) void dwconv3x3_gate_kernel(const T* __restrict__ x, int H, int W, int C, const float* wdw,
-                                                             const float* bdw, T* out, float* partial) {
+__global__ __launch_bounds__(256, 2) void dwconv3x3_gate_kernel(const T* __restrict__ x, int H, int W, int C, const float* wdw,
+                                                                const float* bdw, T* out, float* partial) {
     // wdw: [2C][9] fp32, bdw: [2C].  groups = C/8 divides 256 (C is a power-of-two multiple of 32 here), so a thread keeps
     // the same channel group for its whole grid-stride loop and the SCA pooling is a fixed-order (deterministic) reduction:
     // registers -> LDS -> partial[block][C] -> sca_kernel.
-    // The filters sit in LDS transposed to [tap][2C] (dynamic shared memory, 72*C bytes): a thread reads its 8 + 8 weights of
-    // a tap as four ds_read_b128, and the products take the typed input straight into an fp32 FMA (v_fma_mix_f32 for
-    // f16) - 36 LDS reads + 144 FMAs per 8 output channels where the first version issued 144 global loads + 144
-    // conversions + 144 FMAs.
+    // The filters sit in LDS transposed to [tap][2C] (dynamic shared memory, 72*C bytes).  Per item a thread loads the
+    // GATE_ROWS + 2 input rows x 3 pixels of each gate half with 16-byte loads that have no branch between them (addresses
+    // clamped into the image, values masked to zero outside), every load feeds up to three output rows, and the half's 72
+    // taps sit in registers for the whole column.  (Before: one pixel per thread, 18 loads each behind its own border test
+    // and its own wait, two 64-bit divisions per pixel, the filters re-read from LDS for every pixel.)
     extern __shared__ __attribute__((aligned(16))) float dw_smem[];
     float* wl = dw_smem;                                     // [9][2C]
     float (*red)[8] = reinterpret_cast<float (*)[8]>(dw_smem + 18 * C);  // [256][8]
@@ -420,60 +422,77 @@ __global__ __launch_bounds__(256) void dwconv3x3_gate_kernel(const T* __restrict
         wl[tap * 2 * C + ch] = wdw[i];
     }
     __syncthreads();
-    const int groups = C / 8;
-    const long total = (long)H * W * groups;
+    const unsigned groups = C / 8;
+    const unsigned strips = (H + GATE_ROWS - 1) / GATE_ROWS;
+    const unsigned total = strips * (unsigned)W * groups;    // (strip, x, group), group fastest
     const int g = threadIdx.x % groups;
     float cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    float br[2][8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        br[0][j] = bdw[g * 8 + j];
-        br[1][j] = bdw[C + g * 8 + j];
-    }
-    const float* w1p = wl + g * 8;
-    const float* w2p = wl + C + g * 8;
     using V8 = typename Tr<T>::v8;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const long pix = idx / groups;
-        const int yy = (int)(pix / W), xx = (int)(pix - (long)yy * W);
-        float a1[8], a2[8];
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const unsigned col = idx / groups;                   // strip * W + x
+        const int strip = (int)(col / (unsigned)W), xx = (int)(col - (unsigned)strip * W);
+        const int y0 = strip * GATE_ROWS;
+        float res[GATE_ROWS][8];
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            const int c0 = half * C + g * 8;
+            float wr[9][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            a1[j] = br[0][j];
-            a2[j] = br[1][j];
-        }
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int sy = yy + dy;
-            if (sy < 0 || sy >= H) continue;
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int sx = xx + dx;
-                if (sx < 0 || sx >= W) continue;
-                const T* src = x + ((long)sy * W + sx) * (2 * C);
-                const V8 f1 = __builtin_bit_cast(V8, *reinterpret_cast<const uint4*>(src + g * 8));
-                const V8 f2 = __builtin_bit_cast(V8, *reinterpret_cast<const uint4*>(src + C + g * 8));
-                const int tap = (dy + 1) * 3 + (dx + 1);
-                const f32x4 wa0 = *reinterpret_cast<const f32x4*>(w1p + tap * 2 * C);
-                const f32x4 wa1 = *reinterpret_cast<const f32x4*>(w1p + tap * 2 * C + 4);
-                const f32x4 wb0 = *reinterpret_cast<const f32x4*>(w2p + tap * 2 * C);
-                const f32x4 wb1 = *reinterpret_cast<const f32x4*>(w2p + tap * 2 * C + 4);
+            for (int t = 0; t < 9; ++t) {
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wl + t * 2 * C + c0);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(wl + t * 2 * C + c0 + 4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    a1[j] += (float)f1[j] * wa0[j];
-                    a1[4 + j] += (float)f1[4 + j] * wa1[j];
-                    a2[j] += (float)f2[j] * wb0[j];
-                    a2[4 + j] += (float)f2[4 + j] * wb1[j];
+                    wr[t][j] = w0[j];
+                    wr[t][4 + j] = w1[j];
                 }
             }
-        }
-        float o[8];
+            float acc[GATE_ROWS][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            o[j] = a1[j] * a2[j];
-            cs[j] += o[j];
+            for (int o = 0; o < GATE_ROWS; ++o)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[o][j] = bdw[c0 + j];
+#pragma unroll
+            for (int r = 0; r < GATE_ROWS + 2; ++r) {
+                const int sy = y0 + r - 1;
+                const bool rok = sy >= 0 && sy < H;
+                const int cy = sy < 0 ? 0 : (sy >= H ? H - 1 : sy);
+                V8 f[3];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int sx = xx + dx - 1;
+                    const int cx = sx < 0 ? 0 : (sx >= W ? W - 1 : sx);
+                    f[dx] = __builtin_bit_cast(V8, *reinterpret_cast<const uint4*>(x + ((long)cy * W + cx) * (2 * C) + c0));
+                }
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int sx = xx + dx - 1;
+                    const float m = (rok && sx >= 0 && sx < W) ? 1.f : 0.f;
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (float)f[dx][j] * m;
+#pragma unroll
+                    for (int o = 0; o < GATE_ROWS; ++o) {
+                        const int dy = r - o;
+                        if (dy >= 0 && dy < 3) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[o][j] += v[j] * wr[dy * 3 + dx][j];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < GATE_ROWS; ++o)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) res[o][j] = half ? res[o][j] * acc[o][j] : acc[o][j];
         }
-        *reinterpret_cast<uint4*>(out + pix * C + g * 8) = pack8f<T>(o);
+#pragma unroll
+        for (int o = 0; o < GATE_ROWS; ++o) {
+            if (y0 + o >= H) continue;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cs[j] += res[o][j];
+            *reinterpret_cast<uint4*>(out + ((long)(y0 + o) * W + xx) * C + g * 8) = pack8f<T>(res[o]);
+        }
     }
     if (partial) {
 #pragma unroll
@@ -497,7 +516,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_gate_kernel(const T* __restrict
 }
 
 int dwconv_blocks(int H, int W, int C) {
-    const long total = (long)H * W * (C / 8);
+    const long total = (long)((H + GATE_ROWS - 1) / GATE_ROWS) * W * (C / 8);
     const long b = (total + 255) / 256;
     return (int)(b < DW_MAX_BLOCKS ? b : DW_MAX_BLOCKS);
 }
