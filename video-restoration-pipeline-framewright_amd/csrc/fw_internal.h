@@ -133,6 +133,9 @@ struct PointwiseParams {
     int Win;               // gather2x2: input width; PW_SHUFFLE_UP: low-resolution width
     int Cin;               // gather2x2: input channels (K = 4*Cin)
     const float* a_scale;  // optional per-k scale applied while staging (SCA)
+    const float* ln_w;     // LayerNorm2d fused into the staging (K == 64 == lda, a_f32, no gather): a = norm(a) * ln_w + ln_b
+    const float* ln_b;     //   over the 64 channels of each pixel, eps = ln_eps; null = off
+    float ln_eps;
     const void* wpk;       // pack_pointwise_weights
     const float* bias;     // [32*N_tiles] or null
     int N_tiles;           // cout / 32

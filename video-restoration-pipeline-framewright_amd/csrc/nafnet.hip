@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 #include <cstdio>
+#include <cstdlib>
 #include "fw_internal.h"
 #include "../../include/framewright_hip.h"
 
@@ -59,6 +60,7 @@ struct fw_nafnet {
     DevBuf intro_w, intro_b, ending_w, ending_b;
     bool have_intro_w = false, have_intro_b = false, have_end_w = false, have_end_b = false;
     DevBuf ws;
+    bool fuse_ln = true;   // LayerNorm2d inside the staging pass of the GEMM that follows it at width 64 (FW_NAF_FUSE_LN=0: A/B)
 };
 
 namespace {
@@ -206,10 +208,17 @@ void run_block(fw_nafnet* n, const Block& b, float* S, int H, int W, char* ws, c
     void* T3 = ws + pl.T3;
     float* csum = (float*)(ws + pl.csum);
     float* sca = (float*)(ws + pl.sca);
-    // x = conv1(norm1(inp))
-    launch_layernorm2d(n->dt, S, M, c, (const float*)b.n1w.p, (const float*)b.n1b.p, T1, st);
+    // x = conv1(norm1(inp)); at width 64 (the full-resolution level: four fifths of the LayerNorm bytes) the LayerNorm runs
+    // inside the GEMM's staging pass
+    const bool fuse_ln = c == 64 && n->fuse_ln;
     PointwiseParams p{};
-    p.a = T1; p.lda = c; p.M = M; p.K = c; p.wpk = b.w1.p; p.bias = (const float*)b.b1.p; p.N_tiles = 2 * c / 32;
+    if (fuse_ln) {
+        p.a = S; p.a_f32 = 1; p.ln_w = (const float*)b.n1w.p; p.ln_b = (const float*)b.n1b.p; p.ln_eps = 1e-6f;
+    } else {
+        launch_layernorm2d(n->dt, S, M, c, (const float*)b.n1w.p, (const float*)b.n1b.p, T1, st);
+        p.a = T1;
+    }
+    p.lda = c; p.M = M; p.K = c; p.wpk = b.w1.p; p.bias = (const float*)b.b1.p; p.N_tiles = 2 * c / 32;
     p.mode = PW_STORE; p.out_typed = T2; p.ldo = 2 * c;
     launch_pointwise(n->dt, p, st);
     // x = SimpleGate(conv2(x)); pooled sums for SCA
@@ -221,9 +230,14 @@ void run_block(fw_nafnet* n, const Block& b, float* S, int H, int W, char* ws, c
     p.mode = PW_RESIDUAL; p.out_f32 = S; p.res_f32 = S; p.ldf = c; p.chan_scale = (const float*)b.beta.p;
     launch_pointwise(n->dt, p, st);
     // x = conv5(SimpleGate(conv4(norm2(y)))) ; out = y + x * gamma
-    launch_layernorm2d(n->dt, S, M, c, (const float*)b.n2w.p, (const float*)b.n2b.p, T1, st);
     p = PointwiseParams{};
-    p.a = T1; p.lda = c; p.M = M; p.K = c; p.wpk = b.w4.p; p.bias = (const float*)b.b4.p; p.N_tiles = 2 * c / 32;
+    if (fuse_ln) {
+        p.a = S; p.a_f32 = 1; p.ln_w = (const float*)b.n2w.p; p.ln_b = (const float*)b.n2b.p; p.ln_eps = 1e-6f;
+    } else {
+        launch_layernorm2d(n->dt, S, M, c, (const float*)b.n2w.p, (const float*)b.n2b.p, T1, st);
+        p.a = T1;
+    }
+    p.lda = c; p.M = M; p.K = c; p.wpk = b.w4.p; p.bias = (const float*)b.b4.p; p.N_tiles = 2 * c / 32;
     p.mode = PW_GATE; p.out_typed = T3; p.ldo = c;
     launch_pointwise(n->dt, p, st);
     p = PointwiseParams{};
@@ -306,6 +320,7 @@ int fw_nafnet_create(int device_id, int width, int middle_blk_num, const int* en
         FW_HIP_CHECK(hipGetDeviceCount(&nd));
         if (device_id < 0 || device_id >= nd) throw Error(FW_ERR_INVALID, "fw_nafnet_create: no such device");
         auto n = std::make_unique<fw_nafnet>();
+        if (const char* e = getenv("FW_NAF_FUSE_LN")) n->fuse_ln = atoi(e) != 0;
         n->device = device_id;
         n->dt = (DType)dtype;
         n->width = width;

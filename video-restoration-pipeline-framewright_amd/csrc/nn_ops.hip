@@ -92,7 +92,108 @@ __global__ __launch_bounds__(256, 2) void pointwise_mfma_kernel(const PointwiseP
 
     // staging plan: thread -> (pixel, 16-byte slot), 4 pieces per thread
     const int chunks = p.K / 32;
-    for (int c = 0; c < chunks; ++c) {
+    // LayerNorm2d fused into the staging (K = 64): the four threads that stage a pixel hold its 64 fp32 channels between them
+    // (2 chunks x 8 values each), reduce mean and variance over their quad with two shuffles, and normalise on the way to
+    // LDS - the LayerNorm kernel's pass over HBM (read 256 B, write 128 B per pixel) and the typed re-read are gone.
+    const bool ln = p.ln_w != nullptr;   // uniform
+    float lnv[4][2][8];
+    float ln_mean[4], ln_rstd[4];
+    if (ln) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px = (tid + 256 * i) >> 2, sq = tid & 3;
+            const long m = m0 + px;
+            float sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+                if (m < p.M) {
+                    const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.a) + m * p.lda + c * 32 + sq * 8);
+                    lo = src[0];
+                    hi = src[1];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    lnv[i][c][j] = lo[j];
+                    lnv[i][c][4 + j] = hi[j];
+                    sum += lo[j] + hi[j];
+                }
+            }
+            sum += __shfl_xor(sum, 1);
+            sum += __shfl_xor(sum, 2);
+            ln_mean[i] = sum * (1.f / 64.f);
+            float qq = 0.f;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d = lnv[i][c][j] - ln_mean[i];
+                    qq += d * d;
+                }
+            qq += __shfl_xor(qq, 1);
+            qq += __shfl_xor(qq, 2);
+            ln_rstd[i] = 1.0f / sqrtf(qq * (1.f / 64.f) + p.ln_eps);
+        }
+    }
+    auto consume = [&](int c, const uint4 (&v)[4]) {
+        uint4 wv[(2 * CT * 64 + 255) / 256];
+#pragma unroll
+        for (int i = 0; i < (2 * CT * 64 + 255) / 256; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < 2 * CT * 64) {
+                // fragment order [chunk][ks][cout tile][lane]; this block's cout tiles start at bn*CT (MODE gate: see below)
+                const int ks = idx / (CT * 64), rem = idx - ks * (CT * 64);
+                const int ct = rem >> 6, ln_ = rem & 63;
+                int tile = bn * CT + ct;
+                if (MODE == PW_GATE) tile = bn * (CT / 2) + (ct >> 1) + (ct & 1) * (p.N_tiles / 2);  // pair n with n + N/2
+                wv[i] = tile < p.N_tiles
+                            ? reinterpret_cast<const uint4*>(p.wpk)[(((size_t)c * 2 + ks) * p.N_tiles + tile) * 64 + ln_]
+                            : make_uint4(0, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int px = idx >> 2, s = idx & 3;
+            lds_a[px * 4 + (s ^ ((px >> 2) & 3))] = v[i];
+        }
+#pragma unroll
+        for (int i = 0; i < (2 * CT * 64 + 255) / 256; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < 2 * CT * 64) lds_w[idx] = wv[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 wf[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) wf[ct] = lds_w[(ks * CT + ct) * 64 + lane];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const int px = wave * 64 + pt * 32 + r;
+                const uint4 xf = lds_a[px * 4 + ((2 * ks + h) ^ ((px >> 2) & 3))];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = Tr<T>::mfma(wf[ct], xf, acc[pt][ct]);
+            }
+        }
+    };
+    if (ln) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            uint4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kk = c * 32 + (tid & 3) * 8;
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = (lnv[i][c][j] - ln_mean[i]) * ln_rstd[i] * p.ln_w[kk + j] + p.ln_b[kk + j];
+                v[i] = (m0 + ((tid + 256 * i) >> 2) < p.M) ? pack8f<T>(f) : make_uint4(0, 0, 0, 0);
+            }
+            consume(c, v);
+        }
+    }
+    for (int c = 0; c < (ln ? 0 : chunks); ++c) {
         uint4 v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -138,47 +239,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_mfma_kernel(const PointwiseP
                 }
             }
         }
-        uint4 wv[(2 * CT * 64 + 255) / 256];
-#pragma unroll
-        for (int i = 0; i < (2 * CT * 64 + 255) / 256; ++i) {
-            const int idx = tid + 256 * i;
-            if (idx < 2 * CT * 64) {
-                // fragment order [chunk][ks][cout tile][lane]; this block's cout tiles start at bn*CT (MODE gate: see below)
-                const int ks = idx / (CT * 64), rem = idx - ks * (CT * 64);
-                const int ct = rem >> 6, ln = rem & 63;
-                int tile = bn * CT + ct;
-                if (MODE == PW_GATE) tile = bn * (CT / 2) + (ct >> 1) + (ct & 1) * (p.N_tiles / 2);  // pair n with n + N/2
-                wv[i] = tile < p.N_tiles
-                            ? reinterpret_cast<const uint4*>(p.wpk)[(((size_t)c * 2 + ks) * p.N_tiles + tile) * 64 + ln]
-                            : make_uint4(0, 0, 0, 0);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            const int px = idx >> 2, s = idx & 3;
-            lds_a[px * 4 + (s ^ ((px >> 2) & 3))] = v[i];
-        }
-#pragma unroll
-        for (int i = 0; i < (2 * CT * 64 + 255) / 256; ++i) {
-            const int idx = tid + 256 * i;
-            if (idx < 2 * CT * 64) lds_w[idx] = wv[i];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            uint4 wf[CT];
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) wf[ct] = lds_w[(ks * CT + ct) * 64 + lane];
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt) {
-                const int px = wave * 64 + pt * 32 + r;
-                const uint4 xf = lds_a[px * 4 + ((2 * ks + h) ^ ((px >> 2) & 3))];
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = Tr<T>::mfma(wf[ct], xf, acc[pt][ct]);
-            }
-        }
+        consume(c, v);
     }
 
     // ---- epilogue: lane holds pixel (wave*64 + pt*32 + r), couts 32*tile + 8g + 4h + j ------------------------------
@@ -283,6 +344,8 @@ void launch_pointwise(DType dt, const PointwiseParams& p, hipStream_t st) {
     if (p.M <= 0 || p.K <= 0 || (p.K & 31) || p.N_tiles <= 0) throw Error(1, "pointwise: bad shape");
     if (p.mode == PW_GATE && (p.N_tiles & 1)) throw Error(1, "pointwise: gate needs an even number of cout tiles");
     if (p.gather2x2 && (p.Cin & 31)) throw Error(1, "pointwise: 2x2 gather needs Cin % 32 == 0");
+    if (p.ln_w && (!p.ln_b || !p.a_f32 || p.gather2x2 || p.a_scale || p.K != 64 || p.lda != 64))
+        throw Error(1, "pointwise: fused LayerNorm needs a plain fp32 [M][64] input");
     if (dt == DT_BF16)
         launch_pw_typed<__bf16>(p, st);
     else
