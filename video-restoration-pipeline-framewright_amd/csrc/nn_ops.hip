@@ -253,15 +253,24 @@ __global__ __launch_bounds__(256, 2) void pointwise_mfma_kernel(const PointwiseP
             for (int q = 0; q < CT / 2; ++q) {
                 const int n_base = 32 * (bn * (CT / 2) + q);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = n_base + 8 * g + 4 * h;
-                    float o[4];
+                for (int gp = 0; gp < 2; ++gp) {  // 16-byte stores: see PW_STORE below for the lane exchange
+                    uint2 pk[2];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        o[j] = (acc[pt][2 * q][4 * g + j] + p.bias[n + j]) *
-                               (acc[pt][2 * q + 1][4 * g + j] + p.bias[n + j + p.N_tiles * 16]);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<T*>(p.out_typed) + m * p.ldo + n) =
-                        pack4f<T>(o[0], o[1], o[2], o[3]);
+                    for (int gg = 0; gg < 2; ++gg) {
+                        const int g = 2 * gp + gg;
+                        const int n = n_base + 8 * g + 4 * h;
+                        float o[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            o[j] = (acc[pt][2 * q][4 * g + j] + p.bias[n + j]) *
+                                   (acc[pt][2 * q + 1][4 * g + j] + p.bias[n + j + p.N_tiles * 16]);
+                        pk[gg] = pack4f<T>(o[0], o[1], o[2], o[3]);
+                    }
+                    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                    const u32x2_t sx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+                    const u32x2_t sy = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out_typed) + m * p.ldo + n_base + 16 * gp + 8 * h) =
+                        make_uint4(sx[0], sy[0], sx[1], sy[1]);
                 }
             }
         } else {
@@ -269,6 +278,32 @@ __global__ __launch_bounds__(256, 2) void pointwise_mfma_kernel(const PointwiseP
             for (int ct = 0; ct < CT; ++ct) {
                 const int tile = bn * CT + ct;
                 if (tile >= p.N_tiles) continue;
+                if constexpr (MODE == PW_STORE) {
+                    // typed output, 16 bytes per lane: lanes l and l ^ 32 hold channels 8g + 4h.. of the same pixel; one
+                    // v_permlane32_swap per dword pairs the fragments of groups g, g + 1 so that lane h = 0 owns channels
+                    // 8g..8g+7 and lane h = 1 channels 8g+8..8g+15 (it was four scattered 8-byte stores per 32 channels)
+                    if (p.out_typed && !p.out_f32) {
+#pragma unroll
+                        for (int gp = 0; gp < 2; ++gp) {
+                            uint2 pk[2];
+#pragma unroll
+                            for (int gg = 0; gg < 2; ++gg) {
+                                const int g = 2 * gp + gg;
+                                const int n = 32 * tile + 8 * g + 4 * h;
+                                float o[4];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) o[j] = acc[pt][ct][4 * g + j] + (p.bias ? p.bias[n + j] : 0.f);
+                                pk[gg] = pack4f<T>(o[0], o[1], o[2], o[3]);
+                            }
+                            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                            const u32x2_t sx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+                            const u32x2_t sy = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+                            *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out_typed) + m * p.ldo + 32 * tile + 16 * gp + 8 * h) =
+                                make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                        }
+                        continue;
+                    }
+                }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int n = 32 * tile + 8 * g + 4 * h;
