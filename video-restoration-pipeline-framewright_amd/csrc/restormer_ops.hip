@@ -24,6 +24,74 @@ template <> struct V8<__bf16> { using t = rbf16x8; };
 template <> struct V8<_Float16> { using t = rf16x8; };
 
 // ---- LayerNorm over channels, fp32 [M][ldx] -> typed [M][ldo]; channels [C, Cz) of the output are zeroed ---------------
+// Vector form (C, Cz, ldx, ldo multiples of 4 - every call of the Restormer engine): LPP lanes per pixel, 4 channels per lane
+// and pass (16-byte loads, 8-byte stores), 64 / LPP pixels per wave.  The scalar form below (one wave per pixel, a channel
+// per lane and pass, 2-byte stores) stays for odd shapes.
+template <typename T, int LPP>
+__global__ __launch_bounds__(256) void layernorm_nhwc_vec_kernel(const float* __restrict__ x, long ldx, long M, int C,
+                                                                 const float* __restrict__ w, const float* __restrict__ b,
+                                                                 float eps, T* out, long ldo, int Cz) {
+    constexpr int PPW = 64 / LPP;
+    constexpr int PASSES = LPP == 64 ? 2 : 1;   // C <= 512
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPP, cl = lane % LPP;
+    const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    const long groups = (M + PPW - 1) / PPW;
+    for (long gi = wave0; gi < groups; gi += nwaves) {
+        const long m = gi * PPW + sub;
+        const bool live = m < M;
+        const float* row = x + (live ? m : 0) * ldx;
+        float v[PASSES][4];
+        float s = 0.f;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int c0 = ps * 256 + cl * 4;
+            f4 t = {0.f, 0.f, 0.f, 0.f};
+            if (c0 < C && live) t = *reinterpret_cast<const f4*>(row + c0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[ps][j] = t[j];
+                s += t[j];
+            }
+        }
+#pragma unroll
+        for (int o = LPP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mu = s / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int c0 = ps * 256 + cl * 4;
+            if (c0 < C) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = v[ps][j] - mu;
+                    q += d * d;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = LPP / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+        if (!live) continue;
+        T* orow = out + m * ldo;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int c0 = ps * 256 + cl * 4;
+            if (c0 < Cz) {
+                T o4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    o4[j] = c0 < C ? (T)((v[ps][j] - mu) * rstd * w[c0 + j] + (b ? b[c0 + j] : 0.f)) : (T)0.f;
+                uint2 pk;
+                __builtin_memcpy(&pk, o4, 8);
+                *reinterpret_cast<uint2*>(orow + c0) = pk;
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_nhwc_kernel(const float* __restrict__ x, long ldx, long M, int C,
                                                              const float* __restrict__ w, const float* __restrict__ b,
@@ -428,6 +496,21 @@ int fw_layernorm_nhwc(int dtype, const float* x, long ldx, long M, int C, const 
     if (bad_dtype(dtype) || !x || !weight || !out || M < 1 || C < 1 || C > 512 || zero_to > ldo || C > ldx)
         return rfail(FW_ERR_INVALID, "fw_layernorm_nhwc: bad argument");
     return rguard([&] {
+        const int cz = zero_to > C ? zero_to : C;
+        if (!(C & 3) && !(cz & 3) && !(ldx & 3) && !(ldo & 3) && !((size_t)x & 15) && !((size_t)out & 7)) {
+            const int lanes = (cz + 3) / 4;   // lanes a pixel needs in one pass
+            const int lpp = lanes <= 16 ? 16 : (lanes <= 32 ? 32 : 64);
+            const int blocks = blocks_for((M + 64 / lpp - 1) / (64 / lpp) * 64, 4096);
+#define FW_LNV(T, L) hipLaunchKernelGGL((layernorm_nhwc_vec_kernel<T, L>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, M, C, weight, bias, eps, (T*)out, ldo, cz)
+            if (dtype == FW_DTYPE_BF16) {
+                if (lpp == 16) FW_LNV(__bf16, 16); else if (lpp == 32) FW_LNV(__bf16, 32); else FW_LNV(__bf16, 64);
+            } else {
+                if (lpp == 16) FW_LNV(_Float16, 16); else if (lpp == 32) FW_LNV(_Float16, 32); else FW_LNV(_Float16, 64);
+            }
+#undef FW_LNV
+            FW_HIP_CHECK(hipGetLastError());
+            return;
+        }
         const int blocks = blocks_for(M * 64, 4096);
         if (dtype == FW_DTYPE_BF16)
             hipLaunchKernelGGL((layernorm_nhwc_kernel<__bf16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, M, C, weight,
