@@ -175,10 +175,15 @@ def test_conv_chunk_planar_layout(hip_lib, dtype):
 
 
 @pytest.mark.parametrize("dtype", [_lib.FW_DTYPE_BF16, _lib.FW_DTYPE_F16])
-@pytest.mark.parametrize("na,H,W", [(2, 14, 30), (2, 33, 71), (4, 40, 64), (2, 3, 5), (4, 29, 91)])
-def test_conv_pair_fused(hip_lib, dtype, na, H, W):
-    """conv_a + conv_b fused (csrc/conv3x3_pair.hip) vs two torch convs with x_a rounded to the operand type in between,
-    chunk-planar layout, tile borders (14x30 valid outputs per tile) and image borders (zero padding of x_a)."""
+@pytest.mark.parametrize("slide", ["1", "0"])
+@pytest.mark.parametrize("na,H,W", [(2, 14, 30), (2, 33, 71), (4, 40, 64), (2, 3, 5), (4, 29, 91), (2, 520, 330), (4, 1000, 200),
+                                    (2, 17, 1), (4, 16, 31)])
+def test_conv_pair_fused(hip_lib, dtype, na, H, W, slide, monkeypatch):
+    """conv_a + conv_b fused vs two torch convs with x_a rounded to the operand type in between, chunk-planar layout, tile
+    borders and image borders (zero padding of x_a).  Both forms of the kernel: the sliding window (conv3x3_pair_slide.hip:
+    16-row steps, carried x_a rows, warm-up tiles where a workgroup starts mid-column - the two tall shapes give every
+    workgroup several tiles and column wraps) and the ring kernel (conv3x3_pair.hip: 14x30 valid outputs per tile)."""
+    monkeypatch.setenv("FW_PAIR_SLIDE", slide)
     rng = np.random.default_rng(na * 100 + H)
     cin = 32 * na
     x = torch.from_numpy(rng.standard_normal((H, W, cin)).astype(np.float32)).cuda().to(TDT[dtype])

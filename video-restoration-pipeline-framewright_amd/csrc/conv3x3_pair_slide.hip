@@ -432,12 +432,9 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_slid
     FW_STAMP_FLUSH(p.stamps);
 }
 
-bool pair_slide_enabled() {
-    static const bool on = [] {
-        const char* e = getenv("FW_PAIR_SLIDE");
-        return e ? atoi(e) != 0 : true;
-    }();
-    return on;
+bool pair_slide_enabled() {  // read per launch (a getenv is nothing next to a launch): tests flip it inside one process
+    const char* e = getenv("FW_PAIR_SLIDE");
+    return e ? atoi(e) != 0 : true;
 }
 
 void launch_conv3x3_pair_slide(DType dt, const ConvPairParams& p, int num_cus, hipStream_t stream) {
