@@ -498,11 +498,11 @@ void launch_layernorm2d(DType dt, const float* x, long M, int C, const float* w,
 // per-channel partial sums of the gated output (for the SCA global average pool).  One thread = 8 gated channels of a column
 // of GATE_ROWS output pixels.
 // =====================================================================================================
-constexpr int DW_MAX_BLOCKS = 1024;
+constexpr int DW_MAX_BLOCKS = 768;   // 256 CUs x the 3 blocks that fit on one (168 VGPRs): a 4th round at a third of the occupancy was half the kernel
 constexpr int GATE_ROWS = 3;
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void dwconv3x3_gate_kernel(const T* __restrict__ x, int H, int W, int C, const float* wdw,
+__global__ __launch_bounds__(256, 3) void dwconv3x3_gate_kernel(const T* __restrict__ x, int H, int W, int C, const float* wdw,
                                                                 const float* bdw, T* out, float* partial) {
     // wdw: [2C][9] fp32, bdw: [2C].  groups = C/8 divides 256 (C is a power-of-two multiple of 32 here), so a thread keeps
     // the same channel group for its whole grid-stride loop and the SCA pooling is a fixed-order (deterministic) reduction:
@@ -534,47 +534,49 @@ __global__ __launch_bounds__(256, 2) void dwconv3x3_gate_kernel(const T* __restr
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
             const int c0 = half * C + g * 8;
-            float wr[9][8];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wl + t * 2 * C + c0);
-                const f32x4 w1 = *reinterpret_cast<const f32x4*>(wl + t * 2 * C + c0 + 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    wr[t][j] = w0[j];
-                    wr[t][4 + j] = w1[j];
-                }
-            }
             float acc[GATE_ROWS][8];
 #pragma unroll
             for (int o = 0; o < GATE_ROWS; ++o)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[o][j] = bdw[c0 + j];
+            // one tap column at a time: its GATE_ROWS + 2 input pixels and its three filter rows are all that is live
+            // (24 weights instead of 72: twice the waves per SIMD)
 #pragma unroll
-            for (int r = 0; r < GATE_ROWS + 2; ++r) {
-                const int sy = y0 + r - 1;
-                const bool rok = sy >= 0 && sy < H;
-                const int cy = sy < 0 ? 0 : (sy >= H ? H - 1 : sy);
-                V8 f[3];
+            for (int dx = 0; dx < 3; ++dx) {
+                const int sx = xx + dx - 1;
+                const int cx = sx < 0 ? 0 : (sx >= W ? W - 1 : sx);
+                const bool cok = sx >= 0 && sx < W;
+                V8 f[GATE_ROWS + 2];
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int sx = xx + dx - 1;
-                    const int cx = sx < 0 ? 0 : (sx >= W ? W - 1 : sx);
-                    f[dx] = __builtin_bit_cast(V8, *reinterpret_cast<const uint4*>(x + ((long)cy * W + cx) * (2 * C) + c0));
+                for (int r = 0; r < GATE_ROWS + 2; ++r) {
+                    const int sy = y0 + r - 1;
+                    const int cy = sy < 0 ? 0 : (sy >= H ? H - 1 : sy);
+                    f[r] = __builtin_bit_cast(V8, *reinterpret_cast<const uint4*>(x + ((long)cy * W + cx) * (2 * C) + c0));
+                }
+                float wr[3][8];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wl + (dy * 3 + dx) * 2 * C + c0);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4*>(wl + (dy * 3 + dx) * 2 * C + c0 + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        wr[dy][j] = w0[j];
+                        wr[dy][4 + j] = w1[j];
+                    }
                 }
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int sx = xx + dx - 1;
-                    const float m = (rok && sx >= 0 && sx < W) ? 1.f : 0.f;
+                for (int r = 0; r < GATE_ROWS + 2; ++r) {
+                    const int sy = y0 + r - 1;
+                    const float m = (cok && sy >= 0 && sy < H) ? 1.f : 0.f;
                     float v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = (float)f[dx][j] * m;
+                    for (int j = 0; j < 8; ++j) v[j] = (float)f[r][j] * m;
 #pragma unroll
                     for (int o = 0; o < GATE_ROWS; ++o) {
                         const int dy = r - o;
                         if (dy >= 0 && dy < 3) {
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) acc[o][j] += v[j] * wr[dy * 3 + dx][j];
+                            for (int j = 0; j < 8; ++j) acc[o][j] += v[j] * wr[dy][j];
                         }
                     }
                 }
