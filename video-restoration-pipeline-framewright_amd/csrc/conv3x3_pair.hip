@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_kern
     FW_STAMP_FLUSH(p.stamps);
 }
 
-bool pair_slide_enabled();
+bool pair_slide_enabled(int H, int W, int num_cus);
 void launch_conv3x3_pair_slide(DType dt, const ConvPairParams& p, int num_cus, hipStream_t stream);
 
 static int pair_num_cus() {
@@ -364,7 +364,7 @@ void launch_conv3x3_pair(DType dt, const ConvPairParams& p_in, hipStream_t strea
 #ifdef FW_PAIR_STAMP
     p.stamps = stamp_buffer(0);
 #endif
-    if (pair_slide_enabled()) {  // the sliding-window form (conv3x3_pair_slide.hip); FW_PAIR_SLIDE=0 keeps the kernel below
+    if (pair_slide_enabled(p.H, p.W, pair_num_cus())) {  // the sliding-window form (conv3x3_pair_slide.hip) for all but small frames
         launch_conv3x3_pair_slide(dt, p, pair_num_cus(), stream);
         return;
     }
