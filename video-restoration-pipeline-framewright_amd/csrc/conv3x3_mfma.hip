@@ -481,6 +481,12 @@ static int num_cus() {
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
             v = 256;
+        // FW_CONV_GRID: persistent workgroups per launch (default one per CU); half of them lets two frames run side by side on
+        // two streams, each kernel on its own half of the CUs
+        if (const char* e = getenv("FW_CONV_GRID")) {
+            const int g = atoi(e);
+            if (g > 0 && g < v) v = g;
+        }
         return v;
     }();
     return n;
