@@ -333,8 +333,21 @@ def interfaces() -> None:
             continue
         for n in names:
             out[f"{mod.rsplit('.', 1)[1]}.{n}"] = describe(getattr(m, n))
-    (ROOT / "tests" / "golden" / "interfaces.json").write_text(json.dumps({"classes": out, "not_importable": failed}, indent=1,
-                                                                           sort_keys=True))
+    # module-level tables and the validation messages of the Real-ESRGAN module (pytorch_realesrgan.py:36-61, 264-275)
+    pr = load_reference("framewright.processors.pytorch_realesrgan")
+    tables = {"NCNN_TO_PYTORCH_MODEL": dict(pr.NCNN_TO_PYTORCH_MODEL),
+              "convert_ncnn_model_name": {n: pr.convert_ncnn_model_name(n) for n in
+                                          list(pr.NCNN_TO_PYTORCH_MODEL) + ["unknown", "", "RealESRGAN_x4plus"]},
+              "validate": {}}
+    for kw in ({}, {"model_name": "nope"}, {"scale_factor": 3}, {"scale_factor": 2}, {"model_name": "RealESRGAN_x2plus", "scale_factor": 2},
+               {"model_name": "realesr-animevideov3"}, {"model_name": "RealESRGAN_x4plus_anime_6B"}):
+        try:
+            pr.PyTorchESRGANConfig(**kw).validate()
+            tables["validate"][json.dumps(kw, sort_keys=True)] = None
+        except Exception as e:  # noqa: BLE001
+            tables["validate"][json.dumps(kw, sort_keys=True)] = f"{type(e).__name__}: {e}"
+    (ROOT / "tests" / "golden" / "interfaces.json").write_text(json.dumps({"classes": out, "not_importable": failed, "tables": tables},
+                                                                           indent=1, sort_keys=True))
     print("wrote tests/golden/interfaces.json;", len(out), "classes;", "not importable:", failed)
 
 

@@ -75,3 +75,20 @@ def test_mirror_matches_reference_interface(key):
             if isinstance(v, (set, frozenset)):
                 v = repr(set(v))
             assert v == want, f"{key}.{fname}: {v!r} vs reference {want!r}"
+
+
+def test_module_tables_and_validation_messages_match_reference():
+    """NCNN_TO_PYTORCH_MODEL, convert_ncnn_model_name and PyTorchESRGANConfig.validate() against what the reference module itself
+    returned (pytorch_realesrgan.py:36-61, 264-275)."""
+    t = json.loads((Path(__file__).parent / "golden" / "interfaces.json").read_text())["tables"]
+    assert dict(R.NCNN_TO_PYTORCH_MODEL) == t["NCNN_TO_PYTORCH_MODEL"]
+    for name, want in t["convert_ncnn_model_name"].items():
+        assert R.convert_ncnn_model_name(name) == want, name
+    for kw_json, want in t["validate"].items():
+        cfg = R.PyTorchESRGANConfig(**json.loads(kw_json))
+        if want is None:
+            cfg.validate()
+        else:
+            with pytest.raises(ValueError) as ei:
+                cfg.validate()
+            assert f"ValueError: {ei.value}" == want
