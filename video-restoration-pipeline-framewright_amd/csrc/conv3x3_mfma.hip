@@ -8,18 +8,18 @@
 //
 // GEMM orientation (chosen for NHWC stores, not translated from any CUDA tiling):
 //     D[cout][pixel] += W[cout][k] * X[k][pixel]        k = (tap, cin)
-//   * A operand  = weights, pre-packed on the host into 1-KiB MFMA fragments (one coalesced
-//                  global_load_dwordx4 per wave per fragment, L2 resident, no LDS needed);
-//   * B operand  = activations: a 32-pixel row segment x 16 input channels, read from an LDS halo tile
-//                  with ds_read_b128 (8 consecutive channels of one pixel = 16 bytes per lane);
-//   * D          = v_mfma_f32_32x32x16 accumulators: the PIXEL is on the lane, 4 consecutive output
-//                  channels sit in 4 consecutive registers -> 8-byte NHWC stores straight from registers.
+//   * A operand  = weights, pre-packed on the host into 1-KiB v_mfma_f32_16x16x32 fragments (16 output channels x 32 input
+//                  channels), staged through LDS by LDS-DMA one item ahead;
+//   * B operand  = activations: a 16-pixel half row x 32 input channels, read from an XOR-swizzled LDS halo tile with
+//                  ds_read_b128 (8 consecutive channels of one pixel = 16 bytes per lane);
+//   * D          = the PIXEL is on the lane, 4 consecutive output channels sit in 4 consecutive registers; two tiles'
+//                  fragments are paired with v_permlane16_swap into 16-byte NHWC stores straight from registers.
 //
-// Work decomposition: one 256-thread workgroup (4 waves, one per SIMD) owns a 16x32-pixel output tile; wave w
-// owns rows 4w..4w+3.  K is walked in 32-channel chunks; per chunk the 18x34-pixel halo tile (39 KiB) and the
-// chunk's weight fragments (18 KiB per 32 output channels) are staged global -> LDS by LDS-DMA
-// (global_load_lds_dwordx4) one chunk ahead, with an XOR swizzle that makes the ds_read_b128 fragment reads
-// bank-conflict free; both the halo tile and the weight fragments arrive by LDS-DMA, double buffered.
+// Work decomposition: persistent 512-thread workgroups (8 waves, two per SIMD, 2 output rows each), one per CU, each
+// walking a contiguous XCD-banded range of 16x32-pixel tiles as one flattened (tile, 32-channel chunk) pipeline; per
+// item the 18x34-pixel halo tile (40 KiB) and the chunk's weight fragments arrive by batched LDS-DMA
+// (global_load_lds_dwordx4).  conv_common.h holds the item (conv_item) and the DMA helpers; DESIGN.md section 6 the
+// measurements behind every choice.
 #include <mutex>
 #include <cstdlib>
 #include "fw_internal.h"

@@ -10,8 +10,10 @@
 // Geometry: both convs are evaluated on the same 16x32 "compute region" with the standard 18x34 halo tile.
 // conv_b's zero-padded stencil over x_a is only valid one pixel inside the region, so a tile delivers 14x30 pixels
 // (neighbouring tiles recompute the 1-pixel ring: +22 % MFMA work on these four convs, +12 % on the block, for about
-// half of their HBM reads).  x_a outside the image is zero (= conv_b's zero padding).  The x_a tile doubles as the
-// transpose buffer for the coalesced 16-B global stores of x_a and x_b.
+// half of their HBM reads).  x_a outside the image is zero (= conv_b's zero padding).  Outputs leave the accumulators as
+// 16-byte stores (v_permlane16_swap pairs the fragments of two 16-channel tiles), before the barrier.
+// This is the RING form, used for small frames; conv3x3_pair_slide.hip removes the vertical ring and is the default from
+// about 720p up (launch_conv3x3_pair below chooses).
 #include <mutex>
 #include <type_traits>
 #include <cstdlib>
