@@ -351,6 +351,50 @@ def interfaces() -> None:
     print("wrote tests/golden/interfaces.json;", len(out), "classes;", "not importable:", failed)
 
 
+def aesrgan_attention() -> None:
+    """Fixture set 7 - the reference's own ``AESRGAN`` (aesrgan_face.py:205-269) WITH live attention blocks (gamma != 0; its
+    constructor's zero makes them the identity): scale 2 and 4, square and non-square inputs.  Weights are regenerated from
+    seeds (synth.synthetic_rrdbnet_state / synthetic_attention_state), only inputs and outputs are stored.
+    -> tests/golden/aesrgan_attention.npz"""
+    from framewright_amd.synth import aesrgan_attention_positions, synthetic_attention_state
+    a = load_reference("framewright.processors.aesrgan_face")
+    rng = np.random.default_rng(909)
+    out = {}
+    for tag, (nb, na, scale, h, w, seed) in {"s4": (4, 2, 4, 12, 12, 31), "s2": (2, 2, 2, 9, 14, 32)}.items():
+        sd = synthetic_rrdbnet_state(nb, 4, seed=seed)
+        asd = synthetic_attention_state(nb, na, seed=seed + 100)
+        net = a.AESRGAN(num_in_ch=3, num_out_ch=3, num_feat=64, num_block=nb, scale=scale, num_attention=na).eval()
+        pos = aesrgan_attention_positions(nb, na)
+        ri = 0
+        expect_attn = None
+        for m in net.body:
+            if isinstance(m, a.RRDB):
+                _load_rrdb(m, sd, f"body.{ri}")
+                expect_attn = ri if ri in pos else None
+                ri += 1
+            else:
+                assert isinstance(m, a.AttentionBlock) and expect_attn is not None
+                for name in ("query", "key", "value"):
+                    conv = getattr(m, name)
+                    conv.weight.data.copy_(torch.from_numpy(asd[f"attn.{expect_attn}.{name}.weight"]))
+                    conv.bias.data.copy_(torch.from_numpy(asd[f"attn.{expect_attn}.{name}.bias"]))
+                m.gamma.data.copy_(torch.from_numpy(asd[f"attn.{expect_attn}.gamma"]))
+        assert ri == nb
+        for name in ("conv_first", "conv_body", "conv_up1", "conv_hr", "conv_last") + (("conv_up2",) if scale >= 4 else ()):
+            conv = getattr(net, name)
+            conv.weight.data.copy_(torch.from_numpy(sd[name + ".weight"]))
+            conv.bias.data.copy_(torch.from_numpy(sd[name + ".bias"]))
+        x = rng.uniform(0, 1, size=(1, 3, h, w)).astype(np.float32)
+        with torch.no_grad():
+            y = net(torch.from_numpy(x).clone()).numpy()
+        out[tag + "_cfg"] = np.array([nb, na, scale, seed], np.int64)
+        out[tag + "_in"], out[tag + "_out"] = x, y
+        print(tag, x.shape, "->", y.shape, "mean", float(y.mean()), "std", float(y.std()))
+    dst = ROOT / "tests" / "golden" / "aesrgan_attention.npz"
+    np.savez_compressed(dst, **out)
+    print(f"wrote {dst} ({dst.stat().st_size / 1024:.0f} KiB)")
+
+
 def assign_frames_logic() -> None:
     """Fixture set 6 - `MultiGPUDistributor._assign_frames` (utils/multi_gpu.py:780-870) evaluated by the reference itself for
     every LoadBalanceStrategy on synthetic GPUInfo lists.  -> tests/golden/assign_frames.json"""
@@ -385,3 +429,4 @@ if __name__ == "__main__":
     tile_and_flow_logic()
     interfaces()
     assign_frames_logic()
+    aesrgan_attention()

@@ -46,3 +46,21 @@ def test_x2_front_end_is_pixel_unshuffle():
     with torch.no_grad():
         y = ref.rrdbnet_forward(sd, x, num_block=1, scale=2)
     assert y.shape == (1, 3, 16, 20)
+
+
+def test_aesrgan_with_live_attention_matches_reference(golden_dir):
+    """oracle.aesrgan_forward (RRDB trunk + AttentionBlocks with gamma != 0) against the reference's own AESRGAN module run in
+    the build container (tests/golden/aesrgan_attention.npz, oracle/gen_golden.py aesrgan_attention)."""
+    from framewright_amd.synth import aesrgan_attention_positions, synthetic_attention_state
+    g = np.load(golden_dir / "aesrgan_attention.npz")
+    for tag in ("s4", "s2"):
+        nb, na, scale, seed = (int(v) for v in g[tag + "_cfg"])
+        sd = _sd(nb, seed)
+        asd = {k: torch.from_numpy(v) for k, v in synthetic_attention_state(nb, na, seed=seed + 100).items()}
+        with torch.no_grad():
+            y = ref.aesrgan_forward(sd, asd, torch.from_numpy(g[tag + "_in"]), nb, scale, aesrgan_attention_positions(nb, na)).numpy()
+            y0 = ref.aesrgan_forward(sd, {k: (v * 0 if k.endswith("gamma") else v) for k, v in asd.items()},
+                                     torch.from_numpy(g[tag + "_in"]), nb, scale, aesrgan_attention_positions(nb, na)).numpy()
+        assert y.shape == g[tag + "_out"].shape
+        assert np.abs(y - g[tag + "_out"]).max() < TOL
+        assert np.abs(y0 - g[tag + "_out"]).max() > 50 * TOL      # the attention blocks really contribute to the vectors

@@ -63,6 +63,26 @@ def synthetic_rrdbnet_state(num_block: int, scale: int, seed: int = 1234, num_fe
     return sd
 
 
+def aesrgan_attention_positions(num_block: int, num_attention: int) -> List[int]:
+    """RRDB indices followed by an AttentionBlock (aesrgan_face.py:229: range(0, num_block, num_block // num_attention))."""
+    return sorted(set(range(0, num_block, num_block // num_attention)))
+
+
+def synthetic_attention_state(num_block: int, num_attention: int, seed: int = 77, num_feat: int = 64) -> Dict[str, np.ndarray]:
+    """Seeded parameters of AESRGAN's AttentionBlocks (aesrgan_face.py:142-168): ``attn.{i}.query|key|value.weight|bias`` and
+    ``attn.{i}.gamma`` for the block behind RRDB ``i``; gamma is non-zero (the constructor's zero makes the block inert)."""
+    rng = np.random.default_rng(seed)
+    sd: Dict[str, np.ndarray] = {}
+    for i in aesrgan_attention_positions(num_block, num_attention):
+        bound = 1.0 / np.sqrt(num_feat)
+        for name, cout in (("query", num_feat // 8), ("key", num_feat // 8), ("value", num_feat)):
+            sd[f"attn.{i}.{name}.weight"] = rng.uniform(-bound, bound, size=(cout, num_feat, 1, 1)).astype(np.float32) * \
+                np.float32(4.0 if name != "value" else 1.0)          # sharper logits than the default init: a softmax worth testing
+            sd[f"attn.{i}.{name}.bias"] = rng.uniform(-bound, bound, size=(cout,)).astype(np.float32)
+        sd[f"attn.{i}.gamma"] = np.array([rng.uniform(0.3, 0.9) * (1 if i % 2 == 0 else -1)], np.float32)
+    return sd
+
+
 def synthetic_clip(num_frames: int, height: int, width: int, seed: int) -> Iterator[np.ndarray]:
     """Yields ``num_frames`` uint8 BGR frames (H x W x 3) of smooth moving content + noise."""
     rng = np.random.default_rng(seed)
