@@ -278,6 +278,17 @@ int fw_attn_apply(int dtype, const void* qkv, long stride, long pixels, int v_of
  * cores — what the engine uses; fw_attn_apply is the plain form of the same product. */
 int fw_attn_pack(int dtype, const float* attn, int heads, int ch, int k_pad, void* packed, void* stream);
 
+/* AESRGAN's AttentionBlock (reference src/framewright/processors/aesrgan_face.py:142-168, the in-tree net behind
+ * AESRGANFaceRestorer): attention = softmax(q^T k) over ALL pixels, out = gamma * (v @ attention^T) + x.
+ * fw_attn_softmax_rows: p[i][j] = softmax_j(sum_{c<d} q[i][c] k[j][c]) as an operand-typed [pixels][p_stride] matrix, columns
+ * [pixels, p_stride) zeroed (p_stride = pixels padded to 32).  fw_pack_pointwise_transposed: fw_pack_pointwise's fragments
+ * for the weight W[co][kk] = src[kk][co] from a typed device matrix (W = v^T), so that out = x + gamma * (p @ v) is
+ * fw_pointwise_nhwc(a = p, k = p_stride, res_f32 = x, chan_scale = gamma). */
+int fw_attn_softmax_rows(int dtype, const void* q, long q_stride, const void* k, long k_stride, long pixels, int d, void* p,
+                         long p_stride, void* stream);
+int fw_pack_pointwise_transposed(int dtype, const void* src, long src_stride, long k_valid, int cout, int k_pad, void* packed,
+                                 void* stream);
+
 /* torch.nn.PixelShuffle(2) (unshuffle = 0) / PixelUnshuffle(2) (unshuffle = 1) on fp32 NHWC; low_h x low_w is the
  * low-resolution size, `channels` the channel count at HIGH resolution; dst channels start at dst_coff. */
 int fw_pixel_shuffle2_f32(const float* src, long src_stride, int low_h, int low_w, int channels, float* dst,

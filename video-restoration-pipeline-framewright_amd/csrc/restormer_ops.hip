@@ -461,6 +461,68 @@ __global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restr
     }
 }
 
+// ---- AESRGAN AttentionBlock (reference src/framewright/processors/aesrgan_face.py:142-168): full spatial self-attention ----
+// P[i][j] = softmax_j(sum_c q[i][c] k[j][c]) over ALL pixels j, operand-typed [M][ldp] with columns [M, ldp) zeroed (ldp = M
+// padded to 32: the product P @ v then runs as a 1x1-conv GEMM with K = ldp).  q, k: typed, d <= 8 channels used, 16-byte
+// aligned rows.  One wave per row i: three passes over k (max, sum of exp, write) - k is M x 16 bytes, L2-resident.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_softmax_rows_kernel(const T* __restrict__ q, long ldq, const T* __restrict__ k, long ldk,
+                                                                long M, int d, T* P, long ldp) {
+    using V = typename V8<T>::t;
+    const int lane = threadIdx.x & 63;
+    const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long i = wave0; i < M; i += nwaves) {
+        const V qv = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(q + i * ldq));
+        float qf[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) qf[c] = c < d ? (float)qv[c] : 0.f;
+        auto score = [&](long j) {
+            const V kv = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(k + j * ldk));
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) s += qf[c] * (float)kv[c];
+            return s;
+        };
+        float mx = -3.0e38f;
+        for (long j = lane; j < M; j += 64) mx = fmaxf(mx, score(j));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+        for (long j = lane; j < M; j += 64) sum += expf(score(j) - mx);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float inv = 1.0f / sum;
+        T* row = P + i * ldp;
+        for (long j = lane; j < ldp; j += 64) row[j] = j < M ? (T)(expf(score(j) - mx) * inv) : (T)0.f;
+    }
+}
+
+// fw_pack_pointwise's fragment order built on the device from a typed matrix held TRANSPOSED: W[co][kk] = src[kk][co]
+// (src: typed [K_valid][lds], co < cout; rows kk >= K_valid are zero).  Used for W = v^T in P @ v.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_pointwise_t_kernel(const T* __restrict__ src, long lds_, long K_valid, int cout, int K_pad,
+                                                               T* packed) {
+    const int nt = (cout + 31) / 32, chunks = K_pad / 32;
+    const long total = (long)chunks * 2 * nt * 64;   // 16-byte pieces
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        long r = idx >> 6;
+        const int t = (int)(r % nt);
+        r /= nt;
+        const int ks = (int)(r & 1);
+        const long c = r >> 1;
+        const int co = 32 * t + (lane & 31);
+        const long k0 = 32 * c + 16 * ks + 8 * (lane >> 5);
+        T v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (co < cout && k0 + j < K_valid) ? src[(k0 + j) * lds_ + co] : (T)0.f;
+        uint4 o;
+        __builtin_memcpy(&o, v, 16);
+        reinterpret_cast<uint4*>(packed)[idx] = o;
+    }
+}
+
 static int blocks_for(long n, int cap) {
     const long b = (n + 255) / 256;
     return (int)(b < cap ? (b > 0 ? b : 1) : cap);
@@ -644,6 +706,40 @@ int fw_attn_apply(int dtype, const void* qkv, long ld, long M, int v_off, int he
             hipLaunchKernelGGL((attn_apply_kernel<__bf16>), dim3(blocks), dim3(256), smem, st, (const __bf16*)qkv, ld, M, v_off, heads, ch, attn, (__bf16*)out, ldo, zero_to);
         else
             hipLaunchKernelGGL((attn_apply_kernel<_Float16>), dim3(blocks), dim3(256), smem, st, (const _Float16*)qkv, ld, M, v_off, heads, ch, attn, (_Float16*)out, ldo, zero_to);
+        FW_HIP_CHECK(hipGetLastError());
+    });
+}
+
+int fw_attn_softmax_rows(int dtype, const void* q, long q_stride, const void* k, long k_stride, long pixels, int d, void* p,
+                         long p_stride, void* stream) {
+    if (bad_dtype(dtype) || !q || !k || !p || pixels < 1 || d < 1 || d > 8 || (q_stride & 7) || (k_stride & 7) || p_stride < pixels ||
+        ((size_t)q & 15) || ((size_t)k & 15))
+        return rfail(FW_ERR_INVALID, "fw_attn_softmax_rows: bad argument");
+    return rguard([&] {
+        const int blocks = blocks_for(pixels * 64, 2048);
+        if (dtype == FW_DTYPE_BF16)
+            hipLaunchKernelGGL((attn_softmax_rows_kernel<__bf16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16*)q, q_stride,
+                               (const __bf16*)k, k_stride, pixels, d, (__bf16*)p, p_stride);
+        else
+            hipLaunchKernelGGL((attn_softmax_rows_kernel<_Float16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)q,
+                               q_stride, (const _Float16*)k, k_stride, pixels, d, (_Float16*)p, p_stride);
+        FW_HIP_CHECK(hipGetLastError());
+    });
+}
+
+int fw_pack_pointwise_transposed(int dtype, const void* src, long src_stride, long k_valid, int cout, int k_pad, void* packed,
+                                 void* stream) {
+    if (bad_dtype(dtype) || !src || !packed || k_valid < 1 || cout < 1 || k_pad < k_valid || (k_pad & 31))
+        return rfail(FW_ERR_INVALID, "fw_pack_pointwise_transposed: bad argument");
+    return rguard([&] {
+        const long total = (long)(k_pad / 32) * 2 * ((cout + 31) / 32) * 64;
+        const int blocks = blocks_for(total, 2048);
+        if (dtype == FW_DTYPE_BF16)
+            hipLaunchKernelGGL((pack_pointwise_t_kernel<__bf16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16*)src,
+                               src_stride, k_valid, cout, k_pad, (__bf16*)packed);
+        else
+            hipLaunchKernelGGL((pack_pointwise_t_kernel<_Float16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)src,
+                               src_stride, k_valid, cout, k_pad, (_Float16*)packed);
         FW_HIP_CHECK(hipGetLastError());
     });
 }
