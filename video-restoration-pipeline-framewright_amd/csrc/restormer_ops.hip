@@ -625,7 +625,7 @@ int fw_dwconv3x3_nhwc(int dtype, const void* x, long ldx, int H, int W, int chan
         const int co = mode == 1 ? channels / 2 : channels;
         const int strips = (H + fw::DW_ROWS - 1) / fw::DW_ROWS;
         const int bx = blocks_for((long)W * (co / 8), 1024);
-        const int by_cap = 4096 / bx > 0 ? 4096 / bx : 1;   // every block stages the filters in LDS first: give it several strips
+        const int by_cap = 512 / bx > 0 ? 512 / bx : 1;   // one round of the 512 resident blocks: every block stages the filters in LDS first, so few fat blocks
         const dim3 blocks(bx, strips < by_cap ? strips : by_cap);
         const size_t smem = (size_t)9 * channels * sizeof(float);
         static const bool attr = [] {
