@@ -327,13 +327,16 @@ __global__ __launch_bounds__(256) void attn_gram_kernel(const T* __restrict__ qk
 
 // Sum the partials in block order (one thread per element, coalesced across elements; a fixed order -> deterministic) into
 // the first row of the workspace.
-__global__ __launch_bounds__(256) void attn_reduce_kernel(float* partial, int nblocks, long stride) {
+// Two levels, both in a fixed order (deterministic): thread (e, g) of the first launch sums rows g, g + G, g + 2G, ... into row g
+// (read by nobody else: in place), the second launch (G = 1 over the first G rows) sums those into row 0.
+__global__ __launch_bounds__(256) void attn_reduce_kernel(float* partial, int nblocks, long stride, int G) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= stride) return;
+    const int g = blockIdx.y;
+    if (e >= stride || g >= nblocks) return;
     float s = 0.f;
 #pragma unroll 8
-    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * stride + e];
-    partial[e] = s;   // row 0 is read by its own thread only: in place
+    for (int b = g; b < nblocks; b += G) s += partial[(size_t)b * stride + e];
+    partial[(size_t)g * stride + e] = s;
 }
 
 // A[h][c1][:] = softmax_c2(G / (|q_c1| |k_c2|) * temperature[h]) with F.normalize's clamp (norm >= 1e-12), from the reduced
@@ -667,7 +670,10 @@ int fw_attn_matrix(int dtype, const void* qkv, long ld, long M, int k_off, int h
         else
             hipLaunchKernelGGL((attn_gram_kernel<_Float16>), dim3(nb), dim3(256), smem, st, (const _Float16*)qkv, ld, M, k_off, heads, ch, workspace);
         const long stride = (long)dim * ch + 2 * dim;
-        hipLaunchKernelGGL(attn_reduce_kernel, dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, st, workspace, nb, stride);
+        const int G = nb < 32 ? 1 : 32;
+        if (G > 1)
+            hipLaunchKernelGGL(attn_reduce_kernel, dim3((unsigned)((stride + 255) / 256), G), dim3(256), 0, st, workspace, nb, stride, G);
+        hipLaunchKernelGGL(attn_reduce_kernel, dim3((unsigned)((stride + 255) / 256), 1), dim3(256), 0, st, workspace, G > 1 ? G : nb, stride, 1);
         hipLaunchKernelGGL(attn_finish_kernel, dim3(heads * ch), dim3(128), 0, st, (const float*)workspace, heads, ch, temperature, attn);
         FW_HIP_CHECK(hipGetLastError());
     });
