@@ -271,6 +271,13 @@ int fw_dwconv3x3_nhwc(int dtype, const void* x, long x_stride, int height, int w
 size_t fw_attn_workspace_floats(int heads, int ch);
 int fw_attn_matrix(int dtype, const void* qkv, long stride, long pixels, int k_off, int heads, int ch,
                    const float* temperature, float* workspace, float* attn, void* stream);
+/* fw_attn_matrix on the matrix cores (what the engine runs): q and k are first rewritten pixel-major into `qk_scratch`
+ * (fw_attn_qk_scratch_elems(pixels, heads, ch) operand-typed elements of device memory), then G = q^T k is an MFMA
+ * contraction over the pixel axis; same partial-sum workspace, same deterministic reduction, same result up to fp32
+ * summation order. */
+size_t fw_attn_qk_scratch_elems(long pixels, int heads, int ch);
+int fw_attn_matrix_mfma(int dtype, const void* qkv, long stride, long pixels, int k_off, int heads, int ch,
+                        const float* temperature, float* workspace, void* qk_scratch, float* attn, void* stream);
 int fw_attn_apply(int dtype, const void* qkv, long stride, long pixels, int v_off, int heads, int ch, const float* attn,
                   void* out, long out_stride, int zero_to, void* stream);
 /* The attention matrices as one block-diagonal [k_pad x k_pad] weight in fw_pack_pointwise's fragment order (device buffer of

@@ -80,7 +80,12 @@ def test_attention_matrix_and_apply(hip_lib, dtype, heads, ch, M):
     _lib.check(hip_lib.fw_attn_matrix(dt, P(qd), 3 * cp, M, cp, heads, ch, P(td), P(ws), P(attn), _st()))
     out = torch.full((M, cp), 7.0, dtype=TDT[dtype], device="cuda")
     _lib.check(hip_lib.fw_attn_apply(dt, P(qd), 3 * cp, M, 2 * cp, heads, ch, P(attn), P(out), cp, cp, _st()))
+    # the same matrices from the MFMA Gram path (pixel-major q, k; what the engine runs)
+    attn_m = torch.empty_like(attn)
+    scratch = torch.empty(int(hip_lib.fw_attn_qk_scratch_elems(M, heads, ch)), dtype=TDT[dtype], device="cuda")
+    _lib.check(hip_lib.fw_attn_matrix_mfma(dt, P(qd), 3 * cp, M, cp, heads, ch, P(td), P(ws), P(scratch), P(attn_m), _st()))
     torch.cuda.synchronize()
+    assert (attn_m - attn).abs().max().item() < 1e-5
     f = qkv.float()
     q, k, v = (f[:, t * cp:t * cp + dim].T.reshape(heads, ch, M) for t in range(3))
     a = (F.normalize(q, dim=-1) @ F.normalize(k, dim=-1).transpose(-2, -1)) * temp[:, None, None]

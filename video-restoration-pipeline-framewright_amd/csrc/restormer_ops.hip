@@ -327,6 +327,144 @@ __global__ __launch_bounds__(256) void attn_gram_kernel(const T* __restrict__ qk
 
 // Sum the partials in block order (one thread per element, coalesced across elements; a fixed order -> deterministic) into
 // the first row of the workspace.
+// ---- the same Gram matrices on the matrix cores ------------------------------------------------------------------------------
+// G = q^T k contracts over PIXELS, so the MFMA's k axis must be the pixel axis: lane (row = channel, slot s) of an A / B
+// fragment needs 8 consecutive pixels of one channel - a transposed read of the NHWC tensor.  qk_transpose_kernel writes q and k
+// once as [pixel group of 8][channel][8 pixels] (16 bytes per (group, channel)); a fragment of the Gram kernel is then one
+// 16-byte load per lane, lanes of a 16-lane group on consecutive channels (256 contiguous bytes), no LDS.  Pixels are padded
+// with zeros to a multiple of 32 (one v_mfma_f32_16x16x32 step).
+template <typename T>
+__global__ __launch_bounds__(256) void qk_transpose_kernel(const T* __restrict__ qkv, long ld, long M, long Mp, int k_off, int dim,
+                                                           T* qT, T* kT) {
+    const int d8 = dim >> 3;
+    const long total = (Mp >> 3) * d8 * 2;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(idx % d8);
+        const long r = idx / d8;
+        const int which = (int)(r & 1);
+        const long pg = r >> 1;
+        const T* src = qkv + (which ? k_off : 0) + cg * 8;
+        unsigned short in[8][8];
+#pragma unroll
+        for (int px = 0; px < 8; ++px) {
+            const long p = pg * 8 + px;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (p < M) v = *reinterpret_cast<const uint4*>(src + p * ld);
+            __builtin_memcpy(in[px], &v, 16);
+        }
+        T* dst = (which ? kT : qT) + (pg * dim + cg * 8) * 8;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            unsigned short o[8];
+#pragma unroll
+            for (int px = 0; px < 8; ++px) o[px] = in[px][c];
+            uint4 v;
+            __builtin_memcpy(&v, o, 16);
+            *reinterpret_cast<uint4*>(dst + c * 8) = v;
+        }
+    }
+}
+
+typedef float gram_f4 __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ gram_f4 gram_mfma(uint4 a, uint4 b, gram_f4 c);
+template <>
+__device__ __forceinline__ gram_f4 gram_mfma<__bf16>(uint4 a, uint4 b, gram_f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(rbf16x8, a), __builtin_bit_cast(rbf16x8, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ gram_f4 gram_mfma<_Float16>(uint4 a, uint4 b, gram_f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rf16x8, a), __builtin_bit_cast(rf16x8, b), c, 0, 0, 0);
+}
+
+// grid (blocks, heads).  A block owns a contiguous range of 32-pixel steps, its four waves take every fourth step; a wave
+// keeps all NT x NT 16x16 tiles of its head's ch x ch matrix (NT = ch / 16) plus the per-channel sums of squares, the
+// waves are then added in a fixed order through LDS and the block writes its row of `partial` ([h][c1][c2], sum q^2, sum k^2 -
+// the layout attn_reduce_kernel / attn_finish_kernel read).
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void attn_gram_mfma_kernel(const T* __restrict__ qT, const T* __restrict__ kT, long Mp, int heads,
+                                                             float* partial) {
+    constexpr int ch = 16 * NT;
+    __shared__ float red[NT * NT * 256 + 2 * NT * 16];
+    const int h = blockIdx.y, dim = heads * ch;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, sl = lane >> 4;
+    using V = typename V8<T>::t;
+    const long steps = Mp >> 5;
+    const long s_lo = steps * blockIdx.x / gridDim.x, s_hi = steps * (blockIdx.x + 1) / gridDim.x;
+    gram_f4 acc[NT][NT];
+    float nq[NT], nk[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        nq[i] = nk[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = gram_f4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (long st = s_lo + wave; st < s_hi; st += 4) {
+        const long pg = st * 4 + sl;
+        uint4 a[NT], b[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            a[i] = *reinterpret_cast<const uint4*>(qT + (pg * dim + h * ch + 16 * i + r) * 8);
+            b[i] = *reinterpret_cast<const uint4*>(kT + (pg * dim + h * ch + 16 * i + r) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const V qa = __builtin_bit_cast(V, a[i]), kb = __builtin_bit_cast(V, b[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                nq[i] += (float)qa[e] * (float)qa[e];
+                nk[i] += (float)kb[e] * (float)kb[e];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = gram_mfma<T>(a[i], b[j], acc[i][j]);
+    }
+    // per-channel sums: the four slots of a channel sit in lanes r, r + 16, r + 32, r + 48
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        nq[i] += __shfl_xor(nq[i], 16);
+        nq[i] += __shfl_xor(nq[i], 32);
+        nk[i] += __shfl_xor(nk[i], 16);
+        nk[i] += __shfl_xor(nk[i], 32);
+    }
+    float* rn = red + NT * NT * 256;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float* d = red + ((i * NT + j) * 64 + lane) * 4 + e;
+                        *d = (w ? *d : 0.f) + acc[i][j][e];
+                    }
+            if (sl == 0) {
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    rn[i * 16 + r] = (w ? rn[i * 16 + r] : 0.f) + nq[i];
+                    rn[NT * 16 + i * 16 + r] = (w ? rn[NT * 16 + i * 16 + r] : 0.f) + nk[i];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // D fragment: lane (r, sl) element e = G[c1 = 16 i + 4 sl + e][c2 = 16 j + r]
+    float* out = partial + (size_t)blockIdx.x * ((size_t)dim * ch + 2 * dim);
+    for (int t = threadIdx.x; t < NT * NT * 256; t += 256) {
+        const int e = t & 3, ln = (t >> 2) & 63, ij = t >> 8;
+        const int i = ij / NT, j = ij - i * NT;
+        const int c1 = 16 * i + 4 * (ln >> 4) + e, c2 = 16 * j + (ln & 15);
+        out[((size_t)h * ch + c1) * ch + c2] = red[t];
+    }
+    for (int t = threadIdx.x; t < 2 * NT * 16; t += 256) {
+        const int which = t / (NT * 16), c = t - which * NT * 16;
+        out[(size_t)dim * ch + which * dim + h * ch + c] = rn[t];
+    }
+}
+
 // Two levels, both in a fixed order (deterministic): thread (e, g) of the first launch sums rows g, g + G, g + 2G, ... into row g
 // (read by nobody else: in place), the second launch (G = 1 over the first G rows) sums those into row 0.
 __global__ __launch_bounds__(256) void attn_reduce_kernel(float* partial, int nblocks, long stride, int G) {
@@ -669,6 +807,47 @@ int fw_attn_matrix(int dtype, const void* qkv, long ld, long M, int k_off, int h
             hipLaunchKernelGGL((attn_gram_kernel<__bf16>), dim3(nb), dim3(256), smem, st, (const __bf16*)qkv, ld, M, k_off, heads, ch, workspace);
         else
             hipLaunchKernelGGL((attn_gram_kernel<_Float16>), dim3(nb), dim3(256), smem, st, (const _Float16*)qkv, ld, M, k_off, heads, ch, workspace);
+        const long stride = (long)dim * ch + 2 * dim;
+        const int G = nb < 32 ? 1 : 32;
+        if (G > 1)
+            hipLaunchKernelGGL(attn_reduce_kernel, dim3((unsigned)((stride + 255) / 256), G), dim3(256), 0, st, workspace, nb, stride, G);
+        hipLaunchKernelGGL(attn_reduce_kernel, dim3((unsigned)((stride + 255) / 256), 1), dim3(256), 0, st, workspace, G > 1 ? G : nb, stride, 1);
+        hipLaunchKernelGGL(attn_finish_kernel, dim3(heads * ch), dim3(128), 0, st, (const float*)workspace, heads, ch, temperature, attn);
+        FW_HIP_CHECK(hipGetLastError());
+    });
+}
+
+size_t fw_attn_qk_scratch_elems(long pixels, int heads, int ch) {
+    const long mp = (pixels + 31) / 32 * 32;
+    return (size_t)2 * mp * heads * ch;
+}
+
+int fw_attn_matrix_mfma(int dtype, const void* qkv, long ld, long M, int k_off, int heads, int ch, const float* temperature,
+                        float* workspace, void* qk_scratch, float* attn, void* stream) {
+    const int dim = heads * ch;
+    if (bad_dtype(dtype) || !qkv || !temperature || !workspace || !qk_scratch || !attn || M < 1 || heads < 1 || (ch != 48 && ch != 96) ||
+        dim > 512 || (ld & 7) || (k_off & 7) || ((size_t)qkv & 15) || ((size_t)qk_scratch & 15))
+        return rfail(FW_ERR_INVALID, "fw_attn_matrix_mfma: bad argument");
+    return rguard([&] {
+        hipStream_t st = (hipStream_t)stream;
+        const long Mp = (M + 31) / 32 * 32;
+        const long steps = Mp / 32;
+        long nbl = steps / 8;
+        const int nb = (int)(nbl < 1 ? 1 : (nbl > GRAM_MAX_BLOCKS ? GRAM_MAX_BLOCKS : nbl));
+        const int tb = blocks_for((Mp / 8) * (dim / 8) * 2, 2048);
+        const size_t half = (size_t)Mp * dim;
+#define FW_GM(T)                                                                                                              \
+    do {                                                                                                                      \
+        T* qT = (T*)qk_scratch;                                                                                               \
+        T* kT = qT + half;                                                                                                    \
+        hipLaunchKernelGGL((qk_transpose_kernel<T>), dim3(tb), dim3(256), 0, st, (const T*)qkv, ld, M, Mp, k_off, dim, qT, kT); \
+        if (ch == 48)                                                                                                         \
+            hipLaunchKernelGGL((attn_gram_mfma_kernel<T, 3>), dim3(nb, heads), dim3(256), 0, st, (const T*)qT, (const T*)kT, Mp, heads, workspace); \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((attn_gram_mfma_kernel<T, 6>), dim3(nb, heads), dim3(256), 0, st, (const T*)qT, (const T*)kT, Mp, heads, workspace); \
+    } while (0)
+        if (dtype == FW_DTYPE_BF16) FW_GM(__bf16); else FW_GM(_Float16);
+#undef FW_GM
         const long stride = (long)dim * ch + 2 * dim;
         const int G = nb < 32 ? 1 : 32;
         if (G > 1)

@@ -236,7 +236,8 @@ class RestormerEngine:
             _lib.check(lib.fw_dwconv3x3_nhwc(dt, p(qkv), 3 * cp, h, w, 3 * cp, p(blk["qkv_dw"]), 0, p(qkv2), 3 * cp, st))
             ws = f32(lib.fw_attn_workspace_floats(heads, ch))
             attn = f32(heads, ch, ch)
-            _lib.check(lib.fw_attn_matrix(dt, p(qkv2), 3 * cp, M, cp, heads, ch, p(blk["temp"]), p(ws), p(attn), st))
+            scratch = typ(int(lib.fw_attn_qk_scratch_elems(M, heads, ch)))
+            _lib.check(lib.fw_attn_matrix_mfma(dt, p(qkv2), 3 * cp, M, cp, heads, ch, p(blk["temp"]), p(ws), p(scratch), p(attn), st))
             # attn @ v as a 1x1 convolution with the block-diagonal attention matrix on the MFMA GEMM
             apk = torch.empty(int(lib.fw_pack_pointwise(dt, None, cp, cp, None)), dtype=torch.int16, device=dev)
             _lib.check(lib.fw_attn_pack(dt, p(attn), heads, ch, cp, p(apk), st))
