@@ -13,7 +13,7 @@ from framewright_amd.synth import synthetic_frames, synthetic_rrdbnet_state
 eng = RRDBNetEngine(23, 4, "bf16"); eng.load_state_dict(synthetic_rrdbnet_state(23, 4))
 d = torch.from_numpy(synthetic_frames(1, 1080, 1920, seed=2)[0]).cuda(); o = torch.empty((4320, 7680, 3), dtype=torch.uint8, device="cuda")
 lib = _lib.load()
-buf = (C.c_ulonglong * 64)()
+buf = (C.c_ulonglong * 128)()
 eng.upscale_device(d, out=o); torch.cuda.synchronize()
 for k in (0, 1):
     lib.fw_debug_stamps(k, buf)
@@ -24,10 +24,13 @@ NAMES = [["barrier", "shared-item", "xa-item", "xa-tile+carry", "tile-setup", "v
          ["barrier", "item", "residual-plane", "f32-epi", "tile-setup", "vmcnt", "typed-store"]]
 for k, (title, per_frame) in enumerate([("fused pair kernel", 138), ("64-channel residual conv (conv5, conv_body)", 70)]):
     lib.fw_debug_stamps(k, buf)
-    v = np.array(list(buf), dtype=np.float64).reshape(8, 8)
+    raw = np.array(list(buf), dtype=np.float64)
+    v = raw[:64].reshape(8, 8)
+    mx, sq = raw[64:72], raw[72:80]
     launches = 3 * per_frame * 256
     print(title)
     for w in range(8):
         cyc = v[w, :7].sum()
         print(f"  wave {w}: " + "  ".join(f"{n} {x / cyc:.3f}" for n, x in zip(NAMES[k], v[w, :7]) if n != "-") +
-              f"  | cycles/launch {cyc / launches:.0f}  us/launch {v[w, 7] / launches / 100:.1f}  clock {cyc / v[w, 7] * 0.1:.3f} GHz")
+              f"  | cycles/launch {cyc / launches:.0f}  us/launch {v[w, 7] / launches / 100:.1f}  clock {cyc / v[w, 7] * 0.1:.3f} GHz"
+              f"  slowest workgroup {mx[w] / 100:.1f} us, rms {np.sqrt(sq[w] / launches) / 100:.1f} us")

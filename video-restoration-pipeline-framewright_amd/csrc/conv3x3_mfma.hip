@@ -113,6 +113,9 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
             if (row >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) a_ok |= 1u << i;
         }
         a_all = __builtin_amdgcn_readfirstlane(__all(a_ok == (1u << ACT_ITERS) - 1u)) != 0;
+#ifdef FW_FORCE_SLOW_DMA  // timing experiment: every tile takes the per-piece border path
+        a_all = false;
+#endif
     };
     // the ACT_ITERS pieces of the next activation item
     auto issue_act = [&]() {
@@ -435,15 +438,15 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
 unsigned long long* stamp_buffer(int which) {
     static unsigned long long* buf[2] = {nullptr, nullptr};
     if (!buf[which]) {
-        FW_HIP_CHECK(hipMalloc((void**)&buf[which], 512));
-        FW_HIP_CHECK(hipMemset(buf[which], 0, 512));
+        FW_HIP_CHECK(hipMalloc((void**)&buf[which], 1024));
+        FW_HIP_CHECK(hipMemset(buf[which], 0, 1024));
     }
     return buf[which];
 }
 extern "C" int fw_debug_stamps(int which, unsigned long long* out) {
     if (which < 0 || which > 1) return 1;
-    if (hipMemcpy(out, stamp_buffer(which), 512, hipMemcpyDeviceToHost) != hipSuccess) return 3;
-    (void)hipMemset(stamp_buffer(which), 0, 512);
+    if (hipMemcpy(out, stamp_buffer(which), 1024, hipMemcpyDeviceToHost) != hipSuccess) return 3;
+    (void)hipMemset(stamp_buffer(which), 0, 1024);
     return 0;
 }
 #endif

@@ -195,6 +195,9 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_slid
         // the extra piece only counts on the lanes that issue it
         const unsigned need = ((1u << (NBB * ACT_ITERS)) - 1u) | (extra_lane ? 1u << (2 * ACT_ITERS) : 0u);
         f_all = __builtin_amdgcn_readfirstlane(__all((f_ok & need) == need)) != 0;
+#ifdef FW_FORCE_SLOW_DMA  // timing experiment: every tile takes the per-piece border path
+        f_all = false;
+#endif
     };
     auto issue_act = [&](int stage) {
         if (f_c == 0) plan_tile();

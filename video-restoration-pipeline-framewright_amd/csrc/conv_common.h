@@ -260,8 +260,13 @@ __device__ __forceinline__ void issue_w_half(const char* src, unsigned dst, int 
 #define FW_STAMP_FLUSH(buf)                                                                       \
     do {                                                                                          \
         stamp_acc[7] = __builtin_amdgcn_s_memrealtime() - stamp_rt0;                              \
-        if ((threadIdx.x & 63) == 0 && (buf))                                                     \
+        if ((threadIdx.x & 63) == 0 && (buf)) {                                                   \
             for (int k_ = 0; k_ < 8; ++k_) atomicAdd((buf) + (threadIdx.x >> 6) * 8 + k_, stamp_acc[k_]); \
+            /* entries 64 + wave: the SLOWEST workgroup's lifetime, summed over launches via max-per-launch is not */ \
+            /* possible with one atomic: keep the overall max and the sum of squares for a spread estimate */       \
+            atomicMax((buf) + 64 + (threadIdx.x >> 6), stamp_acc[7]);                             \
+            atomicAdd((buf) + 72 + (threadIdx.x >> 6), stamp_acc[7] * stamp_acc[7]);              \
+        }                                                                                         \
     } while (0)
 unsigned long long* stamp_buffer(int which);
 #else
