@@ -420,8 +420,8 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
                                 const u32x2 sx = __builtin_amdgcn_permlane16_swap(pa.x, pb.x, false, false);
                                 const u32x2 sy = __builtin_amdgcn_permlane16_swap(pa.y, pb.y, false, false);
                                 if (x0 + 16 * ph + q < p.W)
-                                    *reinterpret_cast<uint4*>(lane_base + rowoff + (long)(16 * ph) * p.out_cstride * 2 +
-                                                              (long)c2 * p.out_pstride * 2) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                                    store16(lane_base + rowoff + (long)(16 * ph) * p.out_cstride * 2 + (long)c2 * p.out_pstride * 2,
+                                            make_uint4(sx[0], sy[0], sx[1], sy[1]));
                             }
                     }
                 }

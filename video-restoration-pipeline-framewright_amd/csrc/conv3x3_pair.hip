@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_kern
             for (int ph = 0; ph < 2; ++ph) {
                 const int cp = 16 * ph + q;
                 if (cp >= 1 && cp <= PAIR_TW && (INTERIOR || (unsigned)(ox + cp) < (unsigned)p.W))
-                    *reinterpret_cast<uint4*>(rowbase + (long)(16 * ph) * p.out_cstride * 2 + st_off) = pk[row][ph];
+                    store16(rowbase + (long)(16 * ph) * p.out_cstride * 2 + st_off, pk[row][ph]);
             }
         }
     };

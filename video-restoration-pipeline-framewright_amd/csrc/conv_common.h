@@ -55,6 +55,20 @@ __device__ __forceinline__ f32x4 lrelu4(f32x4 v) {
     return o;
 }
 
+// Output stores.  FW_NT_STORES: as non-temporal (streaming) stores - the outputs are never read again by the kernel that
+// writes them, and whatever sits dirty in the XCDs' L2s when a kernel ends is written back before the next one starts.
+#ifndef FW_NT_STORES
+#define FW_NT_STORES 0
+#endif
+typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16(void* dst, uint4 v) {
+#if FW_NT_STORES
+    __builtin_nontemporal_store(nt_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_u32x4*>(dst));
+#else
+    *reinterpret_cast<uint4*>(dst) = v;
+#endif
+}
+
 constexpr int TILE_H = 16;
 constexpr int TILE_W = 32;
 constexpr int HALO_H = TILE_H + 2;                        // 18
