@@ -429,7 +429,7 @@ extern "C" {
 
 const char* fw_last_error(void) { return fw::last_error_ref().c_str(); }
 
-int fw_abi_version(void) { return 1; }
+int fw_abi_version(void) { return 2; }  // 2: + upscale_u16, resize_lanczos4, grain_addback, attention (softmax rows, transposed pack, MFMA Gram)
 
 int fw_device_count(void) {
     int n = 0;
