@@ -53,7 +53,7 @@ typedef struct fw_nafnet fw_nafnet;
 /* Message of the last failing call on this thread ("" if none).  Never NULL. */
 const char* fw_last_error(void);
 
-/* ABI version of this header (bumped on incompatible change). */
+/* ABI version of this header: 2.  Bumped whenever entry points are added or changed (1 -> 2 was additive). */
 int fw_abi_version(void);
 
 /* Number of visible HIP devices (0 when there is no GPU; never fails). */
