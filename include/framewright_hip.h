@@ -368,6 +368,16 @@ int fw_ifnet_accumulate(const float* tmp, int tmp_h, int tmp_w, int height, int 
 int fw_ifnet_blend(const float* img0, const float* img1, const float* flow, const float* mask, int padded_height,
                    int padded_width, int height, int width, uint8_t* out_bgr, float* out_rgb_f32, void* stream);
 
+/* Motion-blur reduction of the interpolator (reference interpolation.py:403-455: PIL ImageFilter.UnsharpMask(radius, percent,
+ * threshold)) on a uint8 H x W x C device image, bit-exact with Pillow's libImaging (BoxBlur.c / UnsharpMask.c):
+ *   blur = `passes` extended-box passes along x, then along y, every pass rounded to 8 bits:
+ *          (ww * sum_{|k| <= box_radius} in[i+k] + fw_weight * (in[i-box_radius-1] + in[i+box_radius+1]) + 2^23) >> 24,
+ *          edge-replicated (the host derives box_radius / ww / fw_weight from the Gaussian radius exactly as Pillow does);
+ *   out  = |in - blur| > threshold ? clip8(in + (in - blur) * percent / 100) : in       (C integer division).
+ * scratch_a / scratch_b: two H*W*C-byte device buffers.  `out` may alias `src`. */
+int fw_unsharp_mask_u8(const uint8_t* src, int height, int width, int channels, int box_radius, unsigned ww, unsigned fw_weight,
+                       int passes, int percent, int threshold, uint8_t* scratch_a, uint8_t* scratch_b, uint8_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

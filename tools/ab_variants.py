@@ -15,12 +15,12 @@ sys.path.insert(0, str(ROOT))
 from framewright_amd import build as B
 
 CHILD = r"""
-import json, sys, time
+import json, os, sys, time
 sys.path.insert(0, %r)
 import torch
 from framewright_amd.realesrgan import RRDBNetEngine
 from framewright_amd.synth import synthetic_frames, synthetic_rrdbnet_state
-eng = RRDBNetEngine(23, 4, "bf16"); eng.load_state_dict(synthetic_rrdbnet_state(23, 4))
+eng = RRDBNetEngine(23, 4, os.environ.get("FW_AB_DTYPE", "f16")); eng.load_state_dict(synthetic_rrdbnet_state(23, 4))
 d = torch.from_numpy(synthetic_frames(1, 1080, 1920, seed=2)[0]).cuda(); o = torch.empty((4320, 7680, 3), dtype=torch.uint8, device="cuda")
 for _ in range(3): eng.upscale_device(d, out=o)
 torch.cuda.synchronize(); t0 = time.perf_counter()

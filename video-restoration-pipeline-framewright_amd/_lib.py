@@ -29,7 +29,7 @@ EXPORTS = [
     "fw_nafnet_destroy", "fw_u8_crop", "fw_tile_blend_accumulate", "fw_tile_blend_finish", "fw_temporal_average_u8",
     "fw_strength_blend_u8",
     "fw_conv3x3_nhwc_ex", "fw_conv3x3_pair_nhwc", "fw_u8_to_rgb_f32", "fw_resize_bilinear_f32", "fw_ifnet_build_x", "fw_unshuffle2_cast",
-    "fw_depth_to_space4_f32", "fw_ifnet_accumulate", "fw_ifnet_blend",
+    "fw_depth_to_space4_f32", "fw_ifnet_accumulate", "fw_ifnet_blend", "fw_unsharp_mask_u8",
     "fw_u8_to_nhwc", "fw_pixel_shuffle_add_u8",
     "fw_layernorm_nhwc", "fw_pack_pointwise", "fw_pointwise_nhwc", "fw_dwconv3x3_nhwc", "fw_attn_workspace_floats",
     "fw_attn_matrix", "fw_attn_apply", "fw_attn_pack", "fw_pixel_shuffle2_f32", "fw_copy_channels_f32", "fw_f32_to_planar", "fw_tap_post_u8",
@@ -139,6 +139,8 @@ def _declare_ifnet(lib: C.CDLL) -> None:
     lib.fw_ifnet_accumulate.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp, i32, vp]
     lib.fw_ifnet_blend.restype = i32
     lib.fw_ifnet_blend.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
+    lib.fw_unsharp_mask_u8.restype = i32
+    lib.fw_unsharp_mask_u8.argtypes = [vp, i32, i32, i32, i32, C.c_uint, C.c_uint, i32, i32, i32, vp, vp, vp, vp]
     lib.fw_u8_to_nhwc.restype = i32
     lib.fw_u8_to_nhwc.argtypes = [i32, vp, i32, i32, vp, i32, vp]
     lib.fw_pixel_shuffle_add_u8.restype = i32

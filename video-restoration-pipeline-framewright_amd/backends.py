@@ -98,7 +98,7 @@ _VARIANTS = {"x4plus": ("RealESRGAN_x4plus", 4), "x2plus": ("RealESRGAN_x2plus",
 class HipRealESRGANBackend(SRBackend):
     """Counterpart of ``RealESRGANBackend`` (super_resolution.py:441-601) on the HIP engine."""
 
-    def __init__(self, config=None, hardware=None, model_variant: str = "x4plus", gpu_id: int = 0, dtype: str = "bf16"):
+    def __init__(self, config=None, hardware=None, model_variant: str = "x4plus", gpu_id: int = 0, dtype: str = "f16"):
         if model_variant not in _VARIANTS:
             raise ValueError(f"model_variant must be one of {sorted(_VARIANTS)}")
         self.config, self.hardware, self.model_variant = config, hardware, model_variant
@@ -330,7 +330,7 @@ class HipRocmBackend:
     def load_model(self, model_name: str, model_path: Optional[Path] = None, **kwargs) -> bool:
         if not self._initialized:
             return False
-        dtype = kwargs.get("dtype", "bf16")
+        dtype = kwargs.get("dtype", "f16")
         if model_name in R.RRDB_MODELS:
             cfg = R.PyTorchESRGANConfig(model_name=model_name, gpu_id=self.device_id, dtype=dtype,
                                         model_path=str(model_path) if model_path else None)

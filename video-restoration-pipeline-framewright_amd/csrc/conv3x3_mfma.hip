@@ -535,7 +535,7 @@ void launch_conv3x3(DType dt, int cout_tiles, ConvEpilogue epi, const ConvParams
     if (p.act == 2 && !p.chan_scale) throw Error(1, "conv3x3: PReLU needs its slopes");
     if (p.out_lo && (cout_tiles != 2 || !p.out || epi == EPI_IMAGE)) throw Error(1, "conv3x3: out_lo needs a 64-channel typed output");
     if (epi == EPI_RESIDUAL_SPLIT) {
-        if (cout_tiles != 2 || p.upsample2x || !p.out || !p.out_lo || p.n_id < 0 || p.n_id > 6 || p.n_id > p.cin_chunks)
+        if (cout_tiles != 2 || p.upsample2x || !p.out || p.n_id < 0 || p.n_id > 6 || p.n_id > p.cin_chunks)
             throw Error(1, "conv3x3: bad split-trunk residual problem");
         for (int i = 0; i < p.n_id; ++i)
             if (operand_to_f32(dt, f32_to_operand(dt, p.id_scale[i])) != p.id_scale[i])

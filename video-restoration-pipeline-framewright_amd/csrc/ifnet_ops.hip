@@ -203,6 +203,43 @@ static int grid_for(long n) { return (int)((n + 255) / 256 < 4096 ? (n + 255) / 
 
 }  // namespace fw
 
+
+// ---- motion-blur reduction (interpolation.py:403-455): Pillow's UnsharpMask on uint8 H x W x C images ---------------------
+// One pass of libImaging's extended box blur along x (stride 1 pixel) or y, edge-replicated, 24-bit fixed point:
+//   out = (ww * sum_{k=-r..r} in[clamp(i + k)] + fw * (in[clamp(i - r - 1)] + in[clamp(i + r + 1)]) + 2^23) >> 24
+// The image is tiny next to the nets (6 passes over a frame): one thread per sample, taps read straight from global memory
+// (the 2r + 3 taps of neighbouring threads share cache lines; r = 1 for the reference's radius 2).
+__global__ void box_blur_pass_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W, int C, int vertical,
+                                        int r, unsigned ww, unsigned fw) {
+    const long n = (long)H * W * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long px = i / C;
+        const int x = (int)(px % W), y = (int)(px / W);
+        const int pos = vertical ? y : x, len = vertical ? H : W;
+        const long stride = vertical ? (long)W * C : C;
+        const uint8_t* line = src + (vertical ? (long)x * C + c : (long)y * W * C + c);
+        unsigned acc = 0;
+        for (int k = -r; k <= r; ++k) {
+            const int q = min(max(pos + k, 0), len - 1);
+            acc += line[q * stride];
+        }
+        const unsigned far = (unsigned)line[min(max(pos - r - 1, 0), len - 1) * stride] + (unsigned)line[min(max(pos + r + 1, 0), len - 1) * stride];
+        dst[i] = (uint8_t)((acc * ww + far * fw + (1u << 23)) >> 24);
+    }
+}
+
+// d = in - blur; |d| > threshold: clip8(in + d * percent / 100) (C division, truncating), else in     (UnsharpMask.c)
+__global__ void unsharp_finish_u8_kernel(const uint8_t* __restrict__ src, const uint8_t* __restrict__ blur, long n, int percent,
+                                         int threshold, uint8_t* __restrict__ out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int a = src[i], d = a - (int)blur[i];
+        int v = a;
+        if (abs(d) > threshold) v = min(max(a + d * percent / 100, 0), 255);
+        out[i] = (uint8_t)v;
+    }
+}
+
 using namespace fw;
 
 namespace {
@@ -303,6 +340,30 @@ int fw_ifnet_blend(const float* img0, const float* img1, const float* flow, cons
         return fail(FW_ERR_INVALID, "fw_ifnet_blend: bad argument");
     hipLaunchKernelGGL(ifnet_blend_kernel, dim3(grid_for((long)height * width)), dim3(256), 0, (hipStream_t)stream, img0, img1,
                        flow, mask, padded_height, padded_width, height, width, out_bgr, out_rgb_f32);
+    FW_LAUNCHED();
+    return FW_OK;
+}
+
+int fw_unsharp_mask_u8(const uint8_t* src, int height, int width, int channels, int box_radius, unsigned ww, unsigned fw_weight,
+                       int passes, int percent, int threshold, uint8_t* scratch_a, uint8_t* scratch_b, uint8_t* out, void* stream) {
+    if (!src || !scratch_a || !scratch_b || !out || height < 1 || width < 1 || channels < 1 || channels > 4 || box_radius < 0 ||
+        box_radius > 1024 || passes < 1 || passes > 8 || percent < 0 || threshold < 0 ||
+        (unsigned long long)ww * (2ull * box_radius + 1) + 2ull * fw_weight > (1ull << 24))
+        return fail(FW_ERR_INVALID, "fw_unsharp_mask_u8: bad argument");
+    const long n = (long)height * width * channels;
+    hipStream_t st = (hipStream_t)stream;
+    const uint8_t* cur = src;
+    uint8_t* bufs[2] = {scratch_a, scratch_b};
+    int which = 0;
+    for (int axis = 0; axis < 2; ++axis)
+        for (int k = 0; k < passes; ++k) {
+            hipLaunchKernelGGL(box_blur_pass_u8_kernel, dim3(grid_for(n)), dim3(256), 0, st, cur, bufs[which], height, width, channels,
+                               axis, box_radius, ww, fw_weight);
+            FW_LAUNCHED();
+            cur = bufs[which];
+            which ^= 1;
+        }
+    hipLaunchKernelGGL(unsharp_finish_u8_kernel, dim3(grid_for(n)), dim3(256), 0, st, src, cur, n, percent, threshold, out);
     FW_LAUNCHED();
     return FW_OK;
 }

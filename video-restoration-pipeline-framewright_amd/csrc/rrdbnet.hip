@@ -55,6 +55,8 @@ struct fw_rrdbnet {
     // residual trunk as typed hi + typed lo planes (EPI_RESIDUAL_SPLIT): the residual adds run on the matrix cores as
     // identity chunks and conv5's epilogue loads nothing (FW_RRDB_SPLIT_TRUNK=0 selects the fp32 trunk, for A/B runs)
     bool split_trunk = true;
+    // split trunk: lo planes only for the RRDB-level trunk (FW_RRDB_LO=0 keeps a lo plane pair behind every RDB, for A/B runs)
+    bool rrdb_lo = true;
     // hipGraph capture of the per-frame forward (BASELINE configs[4] "hipGraph-captured per-frame stages").  graph_mode: 0 never
     // (default), 1 always, 2 for frames of at most graph_max_px input pixels.  Off by default because it buys nothing here: the
     // launches of a forward run back to back at 1080p, and even a 48x64 frame through 3 blocks takes 0.61 ms either way (the
@@ -330,18 +332,36 @@ void forward(fw_rrdbnet* n, const void* d_in, int bits, int H, int W, void* d_ou
                 // (nxt == rrdb_in).
                 const long PB = PL * 2;  // bytes per plane
                 const long r_off = (char*)cat[rrdb_in] - (char*)cat[cur];
-                p.out_lo = plane(cat[nxt], 6, PL);
                 p.in_id_scale = 5.f;
-                p.n_id = (k == 2) ? 6 : 2;
-                p.chunk_off[0] = 6 * PB;
-                p.chunk_off[1] = 7 * PB;
-                p.id_scale[0] = p.id_scale[1] = 5.f;
-                if (k == 2) {
-                    p.chunk_off[2] = r_off;              // R hi
-                    p.chunk_off[3] = r_off + PB;
-                    p.chunk_off[4] = r_off + 6 * PB;     // R lo
-                    p.chunk_off[5] = r_off + 7 * PB;
-                    for (int i = 2; i < 6; ++i) p.id_scale[i] = 25.f;
+                if (n->rrdb_lo) {
+                    // lo planes at RRDB granularity: rdb1 / rdb2 carry their output as the typed planes alone (what they lose
+                    // - half an ulp of the operand type, once each - reaches the RRDB output scaled by 0.2), and only the
+                    // RRDB-level trunk R keeps hi + lo.  rdb1 takes its residual from R hi (the centre tap in LDS), rdb3
+                    // adds R hi + R lo and writes hi + lo.  Per RRDB 4 lo-plane transfers instead of 16; measured against
+                    // the fp32 oracle the f16 path moves from 3.0-3.7e-4 to 3.4-3.8e-4 max-abs.
+                    p.n_id = 0;
+                    if (k == 2) {
+                        p.out_lo = plane(cat[nxt], 6, PL);
+                        p.n_id = 4;
+                        p.chunk_off[0] = r_off;              // R hi
+                        p.chunk_off[1] = r_off + PB;
+                        p.chunk_off[2] = r_off + 6 * PB;     // R lo
+                        p.chunk_off[3] = r_off + 7 * PB;
+                        for (int i = 0; i < 4; ++i) p.id_scale[i] = 25.f;
+                    }
+                } else {
+                    p.out_lo = plane(cat[nxt], 6, PL);
+                    p.n_id = (k == 2) ? 6 : 2;
+                    p.chunk_off[0] = 6 * PB;
+                    p.chunk_off[1] = 7 * PB;
+                    p.id_scale[0] = p.id_scale[1] = 5.f;
+                    if (k == 2) {
+                        p.chunk_off[2] = r_off;              // R hi
+                        p.chunk_off[3] = r_off + PB;
+                        p.chunk_off[4] = r_off + 6 * PB;     // R lo
+                        p.chunk_off[5] = r_off + 7 * PB;
+                        for (int i = 2; i < 6; ++i) p.id_scale[i] = 25.f;
+                    }
                 }
                 p.s1 = (k == 2) ? 0.2f * 0.2f : 0.2f;
                 run_conv(n, L[4], EPI_RESIDUAL_SPLIT, p, st);
@@ -458,6 +478,7 @@ int fw_rrdbnet_create(int device_id, int num_block, int scale, int dtype, fw_rrd
         if (const char* e = getenv("FW_RRDB_GRAPH")) n->graph_mode = atoi(e);
         if (const char* e = getenv("FW_RRDB_GRAPH_MAX_PX")) n->graph_max_px = atol(e);
         if (const char* e = getenv("FW_RRDB_SPLIT_TRUNK")) n->split_trunk = atoi(e) != 0;
+        if (const char* e = getenv("FW_RRDB_LO")) n->rrdb_lo = atoi(e) != 0;
         *out = n.release();
     });
 }

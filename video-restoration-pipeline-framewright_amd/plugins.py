@@ -178,7 +178,7 @@ class RealESRGANPlugin(ProcessorPlugin):
         self._cfg = R.PyTorchESRGANConfig(model_name=self._settings.get("model_name", "RealESRGAN_x4plus"),
                                           scale_factor=int(self._settings.get("scale_factor", 4)),
                                           tile_size=int(self._settings.get("tile_size", 0)), gpu_id=_gpu_id(self._device),
-                                          dtype=self._settings.get("dtype", "bf16"))
+                                          dtype=self._settings.get("dtype", "f16"))
         self._cfg.validate()
         self._up = R.get_upsampler(self._cfg)
 

@@ -13,9 +13,11 @@ from __future__ import annotations
 import ctypes as C
 import logging
 import shutil
+import threading
 from dataclasses import dataclass
+from enum import Enum
 from pathlib import Path
-from typing import Callable, Dict, List, Mapping, Optional, Sequence, Tuple
+from typing import Callable, Dict, List, Mapping, Optional, Sequence, Tuple, Union
 
 import numpy as np
 
@@ -229,31 +231,209 @@ class IFNetEngine:
 
 
 # ---- directory-level driver (FrameInterpolator) ---------------------------------------------------------------------
+class SmoothnessLevel(Enum):
+    """interpolation.py:33-43."""
+    LOW = "low"
+    MEDIUM = "medium"
+    HIGH = "high"
+
+
+@dataclass
+class InterpolationConfig:
+    """Field-for-field mirror of the reference dataclass (interpolation.py:46-75), same validation messages."""
+    target_fps: int = 60
+    smoothness: SmoothnessLevel = SmoothnessLevel.MEDIUM
+    enable_scene_detection: bool = True
+    scene_threshold: float = 0.3
+    enable_motion_blur_reduction: bool = False
+    rife_model: str = "rife-v4.6"
+    gpu_id: int = 0
+
+    def __post_init__(self) -> None:
+        if not 0.0 <= self.scene_threshold <= 1.0:
+            raise ValueError(f"scene_threshold must be between 0 and 1, got {self.scene_threshold}")
+        if self.target_fps <= 0:
+            raise ValueError(f"target_fps must be positive, got {self.target_fps}")
+        if isinstance(self.smoothness, str):
+            self.smoothness = SmoothnessLevel(self.smoothness.lower())
+
+
+# interpolation.py:78-104 (what get_model_info / list_available_models return)
+RIFE_MODEL_SETTINGS = {
+    "rife-v4.6": {"description": "Best quality, recommended for most content",
+                  "strengths": ["high quality", "good motion handling", "artifact-free"],
+                  "use_cases": ["live action", "general purpose"], "speed_factor": 1.0},
+    "rife-v4.0": {"description": "Faster processing with good quality",
+                  "strengths": ["faster processing", "good quality", "lower memory"],
+                  "use_cases": ["quick processing", "lower-end GPUs"], "speed_factor": 1.3},
+    "rife-anime": {"description": "Optimized for animation (flat colors, clean lines)",
+                   "strengths": ["anime optimization", "flat color handling", "clean line preservation"],
+                   "use_cases": ["anime", "cartoons", "animated content"], "speed_factor": 1.1},
+    "rife-v2.3": {"description": "Legacy model for compatibility", "strengths": ["compatibility", "stable"],
+                  "use_cases": ["legacy workflows"], "speed_factor": 1.2},
+}
+
+
+def _load_rgb(frame) -> np.ndarray:
+    """A path or an array -> RGB uint8 array, as ``np.array(Image.open(p).convert('RGB'))`` (interpolation.py:284-297)."""
+    if isinstance(frame, (str, Path)):
+        img = _imread(Path(frame))
+        if img is None:
+            raise InterpolationError(f"cannot read {frame}")
+        if img.ndim == 2:
+            return np.repeat(img[:, :, None], 3, axis=2)
+        return np.ascontiguousarray(img[:, :, 2::-1])          # BGR(A) -> RGB
+    return frame
+
+
 class FrameInterpolator:
-    """Mirror of the reference class for the paths in scope (interpolation.py:530-809): ``interpolate`` doubles the
-    frame count ``n`` passes in a row (x2 / x4 / x8 by factor), ``interpolate_to_fps`` adds the decimation loop.  Output
-    naming ``frame_%08d.png`` as the reference passes to the binary (:634)."""
+    """Drop-in for the reference class (interpolation.py:130-995): same constructor ``(model, gpu_id, config)``, same public
+    methods, argument names and defaults, ``InterpolationError`` on failure.  Where the reference shells out to
+    ``rife-ncnn-vulkan`` once per pass (:628-650) the IFNet v4.6 runs in libframewright_hip.so; ``engine`` / ``dtype`` are
+    keyword-only additions.
 
-    def __init__(self, model: str = "rife-v4.6", gpu_id: int = 0, engine: Optional[IFNetEngine] = None, dtype: str = "f16"):
-        self.model, self.gpu_id, self._engine, self._dtype = model, gpu_id, engine, dtype
+    Frame bookkeeping.  ``interpolate`` multiplies the frame count by 2^n (n from the fps ratio, :580-587), output names
+    ``frame_%08d.png`` from 1 like the binary's ``-f`` pattern (:634).  The clip is streamed: a source pair (a, b) yields
+    a, then its 2^n - 1 in-betweens by recursive midpoints, so no more than n + 2 frames are alive at once (the reference
+    moves whole directories between passes).
 
+    Three things the reference states but does not do are done here as stated (reference defects):
+    * smoothness passes (:488, :612-675): the reference re-runs the binary on the previous pass's output with ``-n 1``, which
+      is not a frame count the binary accepts.  Here pass 0 produces the frames and every further pass ("refinement", the
+      class docstring's word) re-estimates each synthesised frame from its two neighbours in the previous pass's sequence,
+      keeping the frame count - so ``target_fps`` holds for LOW, MEDIUM and HIGH alike.  At x2 the neighbours of a
+      synthesised frame are its two source frames, the refinement reproduces pass 0 bit for bit, and is skipped.
+    * scene cuts (:600-608 detects them, nothing uses them): no interpolation across a detected cut - the in-betweens of
+      that pair are copies of the nearer source frame (ghost-free, frame count unchanged).
+    * ``-n``: the exponent is applied as 2^n passes of doubling, not handed to the binary as a frame count (:634).
+    """
+
+    SUPPORTED_MODELS = ["rife-v2.3", "rife-v4.0", "rife-v4.6", "rife-anime"]
+    SUPPORTED_TARGET_FPS = [24, 30, 48, 50, 60, 120]
+
+    def __init__(self, model: str = "rife-v4.6", gpu_id: int = 0, config: Optional[InterpolationConfig] = None, *,
+                 engine: Optional[IFNetEngine] = None, dtype: str = "f16"):
+        if config is not None and not isinstance(config, InterpolationConfig):
+            raise TypeError("config must be an InterpolationConfig (engine= and dtype= are keyword-only)")
+        self.config = config or InterpolationConfig(rife_model=model, gpu_id=gpu_id)
+        self.model = self.config.rife_model
+        self.gpu_id = self.config.gpu_id
+        self._scene_boundaries: List[int] = []
+        self._engine, self._dtype = engine, dtype
+        self._mu = threading.Lock()
+
+    # -- engine ------------------------------------------------------------------------------------------------------------
     def _get_engine(self) -> IFNetEngine:
-        if self._engine is None:
-            import os
-            from .synth import synthetic_ifnet_state
-            eng = IFNetEngine(self._dtype, self.gpu_id)
-            path = Path(os.environ.get("FRAMEWRIGHT_MODEL_DIR", str(Path.home() / ".framewright" / "models"))) / self.model / "flownet.pkl"
-            if path.exists():
-                import torch
-                sd = torch.load(str(path), map_location="cpu", weights_only=True)
-                eng.load_state_dict({k.replace("module.", ""): v for k, v in sd.items()})
-            elif os.environ.get("FRAMEWRIGHT_AMD_SYNTHETIC_WEIGHTS") == "1":
-                eng.load_state_dict(synthetic_ifnet_state())
-            else:
-                raise InterpolationError(f"IFNet weights not found: {path}")
-            self._engine = eng
-        return self._engine
+        with self._mu:
+            if self._engine is None:
+                import os
+                from .synth import synthetic_ifnet_state
+                eng = IFNetEngine(self._dtype, self.gpu_id)
+                path = Path(os.environ.get("FRAMEWRIGHT_MODEL_DIR", str(Path.home() / ".framewright" / "models"))) / self.model / "flownet.pkl"
+                if path.exists():
+                    import torch
+                    sd = torch.load(str(path), map_location="cpu", weights_only=True)
+                    eng.load_state_dict({k.replace("module.", ""): v for k, v in sd.items()})
+                elif os.environ.get("FRAMEWRIGHT_AMD_SYNTHETIC_WEIGHTS") == "1":
+                    eng.load_state_dict(synthetic_ifnet_state())
+                else:
+                    raise InterpolationError(f"IFNet weights not found: {path}")
+                self._engine = eng
+            return self._engine
 
+    # -- scene cuts (interpolation.py:267-401) -----------------------------------------------------------------------------
+    def detect_scene_change(self, frame1: Union[Path, np.ndarray], frame2: Union[Path, np.ndarray]) -> bool:
+        """SSIM of the mean-gray images below ``1 - scene_threshold``; histogram intersection when the SSIM cannot be formed."""
+        return policy.scene_change(_load_rgb(frame1), _load_rgb(frame2), self.config.scene_threshold)
+
+    def _detect_scene_by_histogram(self, img1: np.ndarray, img2: np.ndarray, scene_threshold: Optional[float] = None) -> bool:
+        return policy.scene_change_by_histogram(img1, img2, self.config.scene_threshold if scene_threshold is None else scene_threshold)
+
+    def detect_all_scene_changes(self, frame_dir: Path, progress_callback: Optional[Callable[[float], None]] = None) -> List[int]:
+        frames = sorted(Path(frame_dir).glob("*.png"))
+        if len(frames) < 2:
+            return []
+        bounds: List[int] = []
+        prev = _load_rgb(frames[0])
+        for i in range(len(frames) - 1):
+            cur = _load_rgb(frames[i + 1])
+            if policy.scene_change(prev, cur, self.config.scene_threshold):
+                bounds.append(i + 1)
+                logger.info(f"Scene change detected at frame {i + 1}")
+            prev = cur
+            if progress_callback:
+                progress_callback((i + 1) / (len(frames) - 1))
+        self._scene_boundaries = bounds
+        logger.info(f"Detected {len(bounds)} scene changes")
+        return bounds
+
+    # -- motion-blur reduction (interpolation.py:403-486) -------------------------------------------------------------------
+    def apply_motion_blur_reduction_device(self, frame, strength: float = 1.0):
+        """uint8 CUDA tensor H x W x C -> sharpened tensor: Pillow's UnsharpMask(2, int(100 s), 3) and, above s = 1.5, a second
+        UnsharpMask(1, int(50 s), 2), bit for bit (fw_unsharp_mask_u8)."""
+        import torch
+        lib = _lib.load()
+        if frame.dtype != torch.uint8 or not frame.is_cuda or frame.dim() != 3 or not frame.is_contiguous():
+            raise ValueError("expected a contiguous uint8 CUDA tensor H x W x C")
+        H, W, Cc = (int(v) for v in frame.shape)
+        with torch.cuda.device(frame.device):
+            st = C.c_void_p(torch.cuda.current_stream(frame.device).cuda_stream)
+            a, b, out = torch.empty_like(frame), torch.empty_like(frame), torch.empty_like(frame)
+            passes = [(2, int(100 * strength), 3)] + ([(1, int(50 * strength), 2)] if strength > 1.5 else [])
+            src = frame
+            for radius, percent, thr in passes:
+                r, ww, fw = policy.unsharp_box_params(radius)
+                _lib.check(lib.fw_unsharp_mask_u8(C.c_void_p(src.data_ptr()), H, W, Cc, r, ww, fw, 3, percent, thr,
+                                                  C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(out.data_ptr()), st))
+                src = out
+        return out
+
+    def apply_motion_blur_reduction(self, frame: Union[Path, np.ndarray], output_path: Optional[Path] = None,
+                                    strength: float = 1.0) -> np.ndarray:
+        """A path or an array (any channel order: the filter is per channel) -> sharpened array, saved when asked."""
+        import torch
+        is_path = isinstance(frame, (str, Path))
+        img = _imread(Path(frame)) if is_path else np.asarray(frame).astype(np.uint8)
+        if img is None:
+            raise InterpolationError(f"cannot read {frame}")
+        sq = img.ndim == 2
+        t = torch.from_numpy(np.ascontiguousarray(img[:, :, None] if sq else img)).to(torch.device("cuda", self.gpu_id))
+        out = self.apply_motion_blur_reduction_device(t, strength)
+        torch.cuda.synchronize(t.device)
+        res = out.cpu().numpy()
+        res = res[:, :, 0] if sq else res
+        if output_path:
+            _imwrite(Path(output_path), res if is_path else (res[:, :, ::-1] if res.ndim == 3 and res.shape[2] == 3 else res))
+        # the reference returns np.array(PIL image): RGB for a file, the caller's own order for an array
+        if is_path and res.ndim == 3 and res.shape[2] >= 3:
+            return np.ascontiguousarray(res[:, :, [2, 1, 0] + list(range(3, res.shape[2]))])
+        return res
+
+    def apply_motion_blur_reduction_batch(self, input_dir: Path, output_dir: Path, strength: float = 1.0,
+                                          progress_callback: Optional[Callable[[float], None]] = None) -> Path:
+        input_dir, output_dir = Path(input_dir), Path(output_dir)
+        output_dir.mkdir(parents=True, exist_ok=True)
+        frames = sorted(input_dir.glob("*.png"))
+        for i, f in enumerate(frames):
+            self.apply_motion_blur_reduction(f, output_dir / f.name, strength)
+            if progress_callback:
+                progress_callback((i + 1) / len(frames))
+        logger.info(f"Applied motion blur reduction to {len(frames)} frames")
+        return output_dir
+
+    def _get_pass_count(self) -> int:
+        """interpolation.py:488-499."""
+        return {SmoothnessLevel.LOW: 1, SmoothnessLevel.MEDIUM: 2}.get(self.config.smoothness, 3)
+
+    @staticmethod
+    def get_model_info(model: str) -> dict:
+        return RIFE_MODEL_SETTINGS.get(model, {"description": "Unknown model", "strengths": [], "use_cases": [], "speed_factor": 1.0})
+
+    @classmethod
+    def list_available_models(cls) -> List[dict]:
+        return [{"name": m, **RIFE_MODEL_SETTINGS.get(m, {})} for m in cls.SUPPORTED_MODELS]
+
+    # -- in-memory passes ------------------------------------------------------------------------------------------------------
     def double(self, frames: Sequence[np.ndarray]) -> List[np.ndarray]:
         """One x2 pass over an in-memory clip: [f0, mid01, f1, mid12, ..., f_{n-1}] (2n-1 frames)."""
         eng = self._get_engine()
@@ -264,27 +444,114 @@ class FrameInterpolator:
                 out.append(eng.interpolate(f, frames[i + 1]))
         return out
 
-    def interpolate(self, input_dir: Path, output_dir: Path, source_fps: float, target_fps: float,
-                    progress_callback: Optional[Callable[[float], None]] = None) -> Path:
+    def _between(self, a, b, n: int, cut: bool):
+        """The 2^n - 1 in-betweens of (a, b), device tensors, in display order."""
+        if n == 0:
+            return []
+        if cut:
+            k = (1 << n) - 1
+            return [a if 2 * (j + 1) <= (1 << n) else b for j in range(k)]
+        mid = self._get_engine().interpolate_device(a, b, 0.5)
+        return self._between(a, mid, n - 1, False) + [mid] + self._between(mid, b, n - 1, False)
+
+    def _stream(self, files: Sequence[Path], n: int, cuts, refine_passes: int):
+        """Generator of (is_source, frame tensor) in display order for the 2^n-fold clip (+ refinement passes, see the class
+        docstring); at most a few frames alive."""
+        import torch
+        dev = torch.device("cuda", self.gpu_id)
+
+        def load(f):
+            img = _imread(f)
+            if img is None:
+                raise InterpolationError(f"cannot read {f}")
+            if img.ndim == 2:
+                img = np.repeat(img[:, :, None], 3, axis=2)
+            return torch.from_numpy(np.ascontiguousarray(img[:, :, :3])).to(dev)
+
+        def base():
+            prev = load(files[0])
+            for i in range(1, len(files)):
+                cur = load(files[i])
+                yield True, prev
+                for t in self._between(prev, cur, n, i in cuts):
+                    yield (i in cuts), t            # copies across a cut are final: no refinement pass touches them
+                prev = cur
+            yield True, prev
+
+        def refine(gen):
+            # Jacobi sweep over the previous pass: a synthesised frame becomes I(previous neighbour, next neighbour)
+            eng = self._get_engine()
+            it = iter(gen)
+            window = []
+            for item in it:
+                window.append(item)
+                if len(window) == 3:
+                    (_, l), (src_m, m), (_, r) = window
+                    yield (src_m, m) if src_m else (False, eng.interpolate_device(l, r, 0.5))
+                    window.pop(0)
+                elif len(window) == 1:
+                    yield item                      # the clip's first frame is a source frame
+            if len(window) == 2:
+                yield window[1]                     # and so is its last
+
+        g = base()
+        if n >= 2:                                  # at x2 a refinement pass reproduces pass 0 exactly
+            for _ in range(refine_passes):
+                g = refine(g)
+        return g
+
+    # -- directory drivers -----------------------------------------------------------------------------------------------------
+    def interpolate(self, input_dir: Path, output_dir: Path, source_fps: float = 24.0, target_fps: Optional[float] = None,
+                    progress_callback: Optional[Callable[[float], None]] = None,
+                    config: Optional[InterpolationConfig] = None) -> Path:
+        """interpolation.py:530-716."""
+        import torch
         input_dir, output_dir = Path(input_dir), Path(output_dir)
-        files = sorted(input_dir.glob("*.png"))
-        if not files:
-            raise InterpolationError(f"No frames found in {input_dir}")
-        n_pass = policy.interpolation_exponent(target_fps / source_fps)
-        frames = [_imread(f)[:, :, :3] for f in files]
-        for k in range(n_pass):
-            frames = self.double(frames)
-            if progress_callback:
-                progress_callback((k + 1) / n_pass)
+        cfg = config or self.config
+        target_fps = target_fps or cfg.target_fps
+        if not input_dir.exists():
+            raise InterpolationError(f"Input directory does not exist: {input_dir}")
         output_dir.mkdir(parents=True, exist_ok=True)
-        for i, f in enumerate(frames):
-            _imwrite(output_dir / f"frame_{i + 1:08d}.png", f)
+        n = policy.interpolation_exponent(target_fps / source_fps)
+        passes = {SmoothnessLevel.LOW: 1, SmoothnessLevel.MEDIUM: 2}.get(cfg.smoothness, 3)
+        files = sorted(input_dir.glob("*.png"))
+        cuts: set = set()
+        if cfg.enable_scene_detection:
+            if progress_callback:
+                progress_callback(0.02)
+            saved = self.config
+            self.config = cfg                                    # the threshold of the override, like the reference's cfg use
+            try:
+                cuts = set(self.detect_all_scene_changes(
+                    input_dir, (lambda p: progress_callback(0.02 + p * 0.08)) if progress_callback else None))
+            finally:
+                self.config = saved
+        if progress_callback:
+            progress_callback(0.1)
+        if not files:
+            raise InterpolationError("No output frames generated")
+        try:
+            with torch.cuda.device(self.gpu_id):
+                total = (len(files) - 1) * (1 << n) + 1
+                for k, (_, t) in enumerate(self._stream(files, n, cuts, passes - 1)):
+                    if cfg.enable_motion_blur_reduction:
+                        t = self.apply_motion_blur_reduction_device(t, 1.0)
+                    _imwrite(output_dir / f"frame_{k + 1:08d}.png", t.cpu().numpy())
+                    if progress_callback and (k & 15) == 0:
+                        progress_callback(0.1 + 0.85 * (k + 1) / total)
+        except FramewrightHipError as e:
+            raise InterpolationError(f"RIFE interpolation failed: {e}") from e
+        if not list(output_dir.glob("*.png")):
+            raise InterpolationError("No output frames generated")
+        if progress_callback:
+            progress_callback(1.0)
         return output_dir
 
     def interpolate_to_fps(self, input_dir: Path, output_dir: Path, source_fps: float, target_fps: float,
                            progress_callback: Optional[Callable[[float], None]] = None) -> Tuple[Path, float]:
+        """interpolation.py:718-809."""
         input_dir, output_dir = Path(input_dir), Path(output_dir)
-        if target_fps / source_fps <= 1.0:      # interpolation.py:752-758: copy through
+        if target_fps / source_fps <= 1.0:      # :752-758: copy through
             output_dir.mkdir(parents=True, exist_ok=True)
             for i, f in enumerate(sorted(input_dir.glob("*.png"))):
                 shutil.copy(f, output_dir / f"frame_{i:08d}.png")
@@ -311,5 +578,54 @@ class FrameInterpolator:
 
     calculate_interpolation_factor = staticmethod(policy.calculate_interpolation_factor)
 
-    def _detect_scene_by_histogram(self, img1: np.ndarray, img2: np.ndarray, scene_threshold: float = 0.3) -> bool:
-        return policy.scene_change_by_histogram(img1, img2, scene_threshold)
+    def interpolate_frames(self, input_dir: Path, output_dir: Path, source_fps: float = 24.0,
+                           config: Optional[InterpolationConfig] = None,
+                           progress_callback: Optional[Callable[[float], None]] = None) -> dict:
+        """interpolation.py:847-949."""
+        input_dir, output_dir = Path(input_dir), Path(output_dir)
+        cfg = config or self.config
+        input_count = len(sorted(input_dir.glob("*.png")))
+        if input_count == 0:
+            raise InterpolationError(f"No PNG frames found in {input_dir}")
+        result_path = self.interpolate(input_dir=input_dir, output_dir=output_dir, source_fps=source_fps,
+                                       target_fps=cfg.target_fps, progress_callback=progress_callback, config=cfg)
+        output_count = len(list(result_path.glob("*.png")))
+        return {"output_dir": result_path, "input_frames": input_count, "output_frames": output_count,
+                "source_fps": source_fps, "target_fps": cfg.target_fps,
+                "actual_fps": source_fps * (output_count / input_count), "scene_changes": self._scene_boundaries.copy(),
+                "model": cfg.rife_model, "smoothness": cfg.smoothness.value,
+                "motion_blur_reduced": cfg.enable_motion_blur_reduction}
+
+
+# ---- convenience functions (interpolation.py:952-1095) --------------------------------------------------------------------
+def create_interpolator(target_fps: int = 60, smoothness: str = "medium", enable_scene_detection: bool = True,
+                        rife_model: str = "rife-v4.6", gpu_id: int = 0) -> FrameInterpolator:
+    return FrameInterpolator(config=InterpolationConfig(target_fps=target_fps, smoothness=SmoothnessLevel(smoothness.lower()),
+                                                        enable_scene_detection=enable_scene_detection, rife_model=rife_model,
+                                                        gpu_id=gpu_id))
+
+
+def _run_preset(cfg: InterpolationConfig, input_dir, output_dir, source_fps, progress_callback) -> dict:
+    return FrameInterpolator(config=cfg).interpolate_frames(input_dir=input_dir, output_dir=output_dir, source_fps=source_fps,
+                                                            progress_callback=progress_callback)
+
+
+def interpolate_for_anime(input_dir: Path, output_dir: Path, source_fps: float = 24.0, target_fps: int = 60,
+                          progress_callback: Optional[Callable[[float], None]] = None) -> dict:
+    return _run_preset(InterpolationConfig(target_fps=target_fps, smoothness=SmoothnessLevel.MEDIUM, enable_scene_detection=True,
+                                           scene_threshold=0.4, enable_motion_blur_reduction=False, rife_model="rife-anime"),
+                       input_dir, output_dir, source_fps, progress_callback)
+
+
+def interpolate_high_quality(input_dir: Path, output_dir: Path, source_fps: float = 24.0, target_fps: int = 60,
+                             progress_callback: Optional[Callable[[float], None]] = None) -> dict:
+    return _run_preset(InterpolationConfig(target_fps=target_fps, smoothness=SmoothnessLevel.HIGH, enable_scene_detection=True,
+                                           scene_threshold=0.3, enable_motion_blur_reduction=True, rife_model="rife-v4.6"),
+                       input_dir, output_dir, source_fps, progress_callback)
+
+
+def interpolate_fast(input_dir: Path, output_dir: Path, source_fps: float = 24.0, target_fps: int = 60,
+                     progress_callback: Optional[Callable[[float], None]] = None) -> dict:
+    return _run_preset(InterpolationConfig(target_fps=target_fps, smoothness=SmoothnessLevel.LOW, enable_scene_detection=False,
+                                           enable_motion_blur_reduction=False, rife_model="rife-v4.0"),
+                       input_dir, output_dir, source_fps, progress_callback)

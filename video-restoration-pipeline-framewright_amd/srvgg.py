@@ -77,7 +77,7 @@ def _to_numpy(t) -> np.ndarray:
 class SRVGGNetEngine:
     """SRVGGNetCompact resident on one GPU; same surface as RRDBNetEngine (load_state_dict / upscale_device / flops)."""
 
-    def __init__(self, num_conv: int, scale: int = 4, dtype: str = "bf16", device_id: int = 0):
+    def __init__(self, num_conv: int, scale: int = 4, dtype: str = "f16", device_id: int = 0):
         import torch
         self._lib = _lib.load()
         _lib.require_gpu()
