@@ -378,6 +378,27 @@ int fw_ifnet_blend(const float* img0, const float* img1, const float* flow, cons
 int fw_unsharp_mask_u8(const uint8_t* src, int height, int width, int channels, int box_radius, unsigned ww, unsigned fw_weight,
                        int passes, int percent, int threshold, uint8_t* scratch_a, uint8_t* scratch_b, uint8_t* out, void* stream);
 
+/* ---- IFNet v4.6 (RIFE x2 interpolation) as one engine ------------------------------------------------------------------------
+ * Replaces the reference's `rife-ncnn-vulkan` subprocess (reference src/framewright/processors/interpolation.py:628-650; model
+ * directory `rife-v4.6`, :106-124).  Same life cycle as fw_rrdbnet / fw_nafnet: create, set every tensor of the Practical-RIFE
+ * IFNet_HDv3 state dict (fp32, PyTorch layouts; keys `block{0..3}.conv0.{0,1}.0.{weight,bias}`,
+ * `block{i}.convblock.{0..7}.conv.{weight,bias}`, `block{i}.convblock.{j}.beta`, `block{i}.lastconv.0.{weight,bias}`),
+ * finalize (weight transforms + MFMA fragment packing on the host, upload), then any number of fw_ifnet_interp_u8 calls.
+ * One handle per GPU; calls on a handle are serialised by an internal mutex.  FW_IFNET_GRAPH=1 in the environment replays a
+ * captured hipGraph when a call repeats (frame size, timestep, buffer addresses). */
+typedef struct fw_ifnet fw_ifnet;
+int fw_ifnet_create(int device_id, int dtype, fw_ifnet** out);
+int fw_ifnet_set_tensor(fw_ifnet* net, const char* key, const float* data, size_t numel);
+int fw_ifnet_finalize(fw_ifnet* net);
+/* frame0 / frame1: uint8 BGR H x W x 3 (both FW_HOST or both FW_DEVICE); timestep in (0, 1) (0.5 = the mid frame of a x2 pass);
+ * out_bgr = round_half_even(clamp(merged, 0, 1) * 255) BGR and/or out_rgb_f32 = merged RGB float (device), either may be NULL.
+ * Asynchronous on `stream` for device buffers; host outputs are complete on return. */
+int fw_ifnet_interp_u8(fw_ifnet* net, const uint8_t* frame0, const uint8_t* frame1, int in_loc, int height, int width,
+                       float timestep, uint8_t* out_bgr, int out_loc, float* out_rgb_f32, void* stream);
+size_t fw_ifnet_workspace_bytes(const fw_ifnet* net, int height, int width);
+double fw_ifnet_flops(const fw_ifnet* net, int height, int width);
+int fw_ifnet_destroy(fw_ifnet* net);
+
 #ifdef __cplusplus
 }
 #endif

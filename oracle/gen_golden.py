@@ -323,6 +323,7 @@ def interfaces() -> None:
         "framewright.plugins.base": ["ProcessorPlugin", "PluginMetadata"],
         "framewright.infrastructure.gpu.backends.base": ["Backend", "BackendCapabilities"],
         "framewright.processors.temporal_denoise": ["FlowField"],
+        "framewright.processors.interpolation": ["InterpolationConfig", "FrameInterpolator"],
     }
     out, failed = {}, {}
     for mod, names in wanted.items():
@@ -395,6 +396,60 @@ def aesrgan_attention() -> None:
     print(f"wrote {dst} ({dst.stat().st_size / 1024:.0f} KiB)")
 
 
+def interpolator_logic() -> None:
+    """Fixture set 8 - processors/interpolation.py host logic evaluated by the reference's own ``FrameInterpolator`` (binary
+    lookup patched, nothing downloaded) and by Pillow (the third-party package its motion-blur reduction calls, present here):
+    pass counts (:488-499), InterpolationConfig validation messages (:66-75), model info tables (:501-528),
+    ``detect_all_scene_changes`` on a PNG directory (:368-401; skimage is absent, so the reference itself takes its
+    histogram branch), ``apply_motion_blur_reduction`` (:403-455) at three strengths.
+    -> tests/golden/interpolator_reference.npz + .json"""
+    import json
+    import shutil
+    import tempfile
+    from unittest import mock
+
+    from PIL import Image
+
+    ip = load_reference("framewright.processors.interpolation")
+    with mock.patch.object(shutil, "which", return_value="/usr/bin/true"):
+        mk = lambda **kw: ip.FrameInterpolator(config=ip.InterpolationConfig(**kw))
+        passes = {lvl: mk(smoothness=lvl)._get_pass_count() for lvl in ("low", "medium", "high")}
+        fi = mk(scene_threshold=0.3)
+        errors = {}
+        for kw in ({"scene_threshold": 1.5}, {"scene_threshold": -0.1}, {"target_fps": 0}, {"smoothness": "ultra"}):
+            try:
+                ip.InterpolationConfig(**kw)
+                errors[json.dumps(kw, sort_keys=True)] = None
+            except Exception as e:  # noqa: BLE001
+                errors[json.dumps(kw, sort_keys=True)] = f"{type(e).__name__}: {e}"
+        info = {m: ip.FrameInterpolator.get_model_info(m) for m in ip.FrameInterpolator.SUPPORTED_MODELS + ["nope"]}
+        models = ip.FrameInterpolator.list_available_models()
+        # a 7-frame clip with two cuts: smooth drift, a hard cut to another scene, drift, a cut back
+        rng = np.random.default_rng(11)
+        yy, xx = np.mgrid[0:40, 0:56]
+        scene_a = np.stack([120 + 80 * np.sin(xx / 9.0 + c) + 30 * np.cos(yy / 7.0) for c in range(3)], 2)
+        scene_b = np.stack([60 + 150 * ((xx // 8 + yy // 8 + c) % 2) for c in range(3)], 2)
+        clip = []
+        for k, base in enumerate([scene_a, scene_a, scene_a, scene_b, scene_b, scene_a, scene_a]):
+            clip.append(np.clip(np.roll(base, k, axis=1) + rng.normal(0, 3, base.shape), 0, 255).astype(np.uint8))
+        with tempfile.TemporaryDirectory() as td:
+            for k, f in enumerate(clip):
+                Image.fromarray(f).save(Path(td) / f"frame_{k:08d}.png")
+            bounds = fi.detect_all_scene_changes(Path(td))
+            pair_flags = [bool(fi.detect_scene_change(Path(td) / f"frame_{k:08d}.png", Path(td) / f"frame_{k + 1:08d}.png"))
+                          for k in range(len(clip) - 1)]
+        img = np.clip(np.stack([128 + 90 * np.sin(xx / 3.0 + c) * np.cos(yy / 4.0) for c in range(3)], 2)
+                      + rng.normal(0, 6, (40, 56, 3)), 0, 255).astype(np.uint8)
+        sharp = {f"sharp_{s}": fi.apply_motion_blur_reduction(img, strength=s) for s in (0.5, 1.0, 2.0)}
+    np.savez_compressed(ROOT / "tests" / "golden" / "interpolator_reference.npz", clip=np.stack(clip), img=img,
+                        **{k.replace(".", "p"): v for k, v in sharp.items()})
+    (ROOT / "tests" / "golden" / "interpolator_reference.json").write_text(json.dumps(
+        {"pass_count": passes, "config_errors": errors, "model_info": info, "models": models, "scene_boundaries": bounds,
+         "pair_flags": pair_flags, "has_skimage": bool(ip.HAS_SKIMAGE), "supported_models": ip.FrameInterpolator.SUPPORTED_MODELS,
+         "supported_target_fps": ip.FrameInterpolator.SUPPORTED_TARGET_FPS}, indent=1, sort_keys=True))
+    print("wrote tests/golden/interpolator_reference.{npz,json}; scene boundaries", bounds, "skimage", ip.HAS_SKIMAGE)
+
+
 def assign_frames_logic() -> None:
     """Fixture set 6 - `MultiGPUDistributor._assign_frames` (utils/multi_gpu.py:780-870) evaluated by the reference itself for
     every LoadBalanceStrategy on synthetic GPUInfo lists.  -> tests/golden/assign_frames.json"""
@@ -430,3 +485,4 @@ if __name__ == "__main__":
     interfaces()
     assign_frames_logic()
     aesrgan_attention()
+    interpolator_logic()

@@ -13,6 +13,7 @@ import pytest
 from framewright_amd import backends as B
 from framewright_amd import plugins as PL
 from framewright_amd import realesrgan as R
+from framewright_amd import rife as RF
 from framewright_amd import tap_denoise as T
 from framewright_amd import temporal_denoise as TD
 
@@ -35,6 +36,8 @@ MIRRORS = {
     "base.Backend": B.HipRocmBackend,
     "base.BackendCapabilities": B.BackendCapabilities,
     "temporal_denoise.FlowField": TD.FlowField,
+    "interpolation.InterpolationConfig": RF.InterpolationConfig,
+    "interpolation.FrameInterpolator": RF.FrameInterpolator,
 }
 
 

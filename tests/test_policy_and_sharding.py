@@ -79,21 +79,44 @@ def _combine(window, start, center, n):
     return tap_ref.temporal_average(window, ws)
 
 
-def _worker(rank, world, port, frames, q):
+def _worker(rank, world, port, frames, q, as_tensors=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        den = S.sharded_temporal_denoise(frames, 2, _fake_denoise, _combine)
+        if as_tensors:      # the device-resident form: tensors in, tensors (halos included) through, no numpy staging
+            import torch
+            tf = [torch.from_numpy(f) for f in frames]
+            den = S.sharded_temporal_denoise(tf, 2, lambda t: torch.from_numpy(_fake_denoise(t.numpy())),
+                                             lambda w, s, c, n: _combine([t.numpy() for t in w], s, c, n))
+            mid = S.sharded_pairs(tf, lambda a, b: ((a.to(torch.int32) + b.to(torch.int32)) // 2).to(torch.uint8))
+            mid = {k: v.numpy() for k, v in mid.items()}
+        else:
+            den = S.sharded_temporal_denoise(frames, 2, _fake_denoise, _combine)
+            mid = S.sharded_pairs(frames, lambda a, b: ((a.astype(np.uint16) + b) // 2).astype(np.uint8))
         up = S.sharded_upscale(frames, lambda f: np.repeat(np.repeat(f, 2, 0), 2, 1))
-        mid = S.sharded_pairs(frames, lambda a, b: ((a.astype(np.uint16) + b) // 2).astype(np.uint8))
         q.put((rank, den, {k: v.shape for k, v in up.items()}, mid))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_frames", [7, 10])
-def test_two_rank_sharding_equals_single_process(n_frames):
+def test_block_partition_with_fewer_frames_than_ranks():
+    # ranks without frames sit at the end, and every rank derives the same table
+    assert S.block_partition(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    assert S.block_partition(3, 4, 2) == [(0, 3), (3, 3), (3, 3), (3, 3)]
+    assert S.block_partition(0, 3) == [(0, 0)] * 3
+    assert S.block_partition(9, 4, 2) == [(0, 2), (2, 4), (4, 6), (6, 9)]
+    for n in range(0, 12):
+        for world in (1, 2, 3, 4, 8):
+            for r in (1, 2, 3):
+                plans = [S.temporal_halo_plan(n, world, k, r) for k in range(world)]
+                for k in range(world - 1):   # both ends of every link agree on what crosses it
+                    assert plans[k][2][0] == plans[k + 1][1][1] and plans[k][2][1] == plans[k + 1][1][0]
+                assert plans[0][1] == (0, 0) and plans[-1][2] == (0, 0)
+
+
+@pytest.mark.parametrize("n_frames,world,as_tensors", [(7, 2, False), (10, 2, False), (10, 2, True), (2, 4, False), (3, 4, True), (5, 3, False)])
+def test_two_rank_sharding_equals_single_process(n_frames, world, as_tensors):
     rng = np.random.default_rng(n_frames)
     frames = [rng.integers(0, 256, size=(12, 16, 3), dtype=np.uint8) for _ in range(n_frames)]
     want_den = {i: _combine([_fake_denoise(f) for f in frames[max(0, i - 2):i + 3]], max(0, i - 2), i, n_frames)
@@ -102,7 +125,7 @@ def test_two_rank_sharding_equals_single_process(n_frames):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, frames, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, frames, q, as_tensors)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=120) for _ in procs]
@@ -111,8 +134,8 @@ def test_two_rank_sharding_equals_single_process(n_frames):
         assert p.exitcode == 0
     den, ups, mid = {}, {}, {}
     for rank, d, u, m in got:
-        assert set(d) == set(range(*S.block_partition(n_frames, 2)[rank]))       # block partition, no overlap
-        assert set(u) == set(S.round_robin_assignment(n_frames, 2)[rank])        # round-robin for SR
+        assert set(d) == set(range(*S.block_partition(n_frames, world, 2)[rank]))   # block partition, no overlap
+        assert set(u) == set(S.round_robin_assignment(n_frames, world)[rank])       # round-robin for SR
         den.update(d)
         ups.update(u)
         mid.update(m)

@@ -30,6 +30,8 @@ EXPORTS = [
     "fw_strength_blend_u8",
     "fw_conv3x3_nhwc_ex", "fw_conv3x3_pair_nhwc", "fw_u8_to_rgb_f32", "fw_resize_bilinear_f32", "fw_ifnet_build_x", "fw_unshuffle2_cast",
     "fw_depth_to_space4_f32", "fw_ifnet_accumulate", "fw_ifnet_blend", "fw_unsharp_mask_u8",
+    "fw_ifnet_create", "fw_ifnet_set_tensor", "fw_ifnet_finalize", "fw_ifnet_interp_u8", "fw_ifnet_workspace_bytes", "fw_ifnet_flops",
+    "fw_ifnet_destroy",
     "fw_u8_to_nhwc", "fw_pixel_shuffle_add_u8",
     "fw_layernorm_nhwc", "fw_pack_pointwise", "fw_pointwise_nhwc", "fw_dwconv3x3_nhwc", "fw_attn_workspace_floats",
     "fw_attn_matrix", "fw_attn_apply", "fw_attn_pack", "fw_pixel_shuffle2_f32", "fw_copy_channels_f32", "fw_f32_to_planar", "fw_tap_post_u8",
@@ -139,6 +141,20 @@ def _declare_ifnet(lib: C.CDLL) -> None:
     lib.fw_ifnet_accumulate.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp, i32, vp]
     lib.fw_ifnet_blend.restype = i32
     lib.fw_ifnet_blend.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
+    lib.fw_ifnet_create.restype = i32
+    lib.fw_ifnet_create.argtypes = [i32, i32, C.POINTER(vp)]
+    lib.fw_ifnet_set_tensor.restype = i32
+    lib.fw_ifnet_set_tensor.argtypes = [vp, C.c_char_p, vp, sz]
+    lib.fw_ifnet_finalize.restype = i32
+    lib.fw_ifnet_finalize.argtypes = [vp]
+    lib.fw_ifnet_interp_u8.restype = i32
+    lib.fw_ifnet_interp_u8.argtypes = [vp, vp, vp, i32, i32, i32, f32, vp, i32, vp, vp]
+    lib.fw_ifnet_workspace_bytes.restype = sz
+    lib.fw_ifnet_workspace_bytes.argtypes = [vp, i32, i32]
+    lib.fw_ifnet_flops.restype = C.c_double
+    lib.fw_ifnet_flops.argtypes = [vp, i32, i32]
+    lib.fw_ifnet_destroy.restype = i32
+    lib.fw_ifnet_destroy.argtypes = [vp]
     lib.fw_unsharp_mask_u8.restype = i32
     lib.fw_unsharp_mask_u8.argtypes = [vp, i32, i32, i32, i32, C.c_uint, C.c_uint, i32, i32, i32, vp, vp, vp, vp]
     lib.fw_u8_to_nhwc.restype = i32
@@ -227,3 +243,28 @@ def require_gpu() -> int:
     if n <= 0:
         raise FramewrightHipError(FW_ERR_HIP, "no HIP device visible: framewright_amd has no CPU fallback")
     return n
+
+
+def on_tensor_device(fn):
+    """Decorator for device-level entry methods: run the body with the CUDA device of the first tensor argument current, so
+    that ``torch.cuda.current_stream()``, scratch allocations and the library's block-level launchers (which launch on the
+    current device: zero pages, default streams) all refer to the device that owns the buffers - an engine created with
+    ``device_id != 0`` must not depend on the caller's current device."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        import torch
+        dev = None
+        for a in list(args) + list(kwargs.values()):
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                dev = a.device
+                break
+            if isinstance(a, (list, tuple)) and a and isinstance(a[0], torch.Tensor) and a[0].is_cuda:
+                dev = a[0].device
+                break
+        if dev is None:
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapped

@@ -181,6 +181,20 @@ void launch_grain_addback(const uint8_t* orig, const uint8_t* den, int H, int W,
 void launch_resize_lanczos4_u8(const uint8_t* src, int Hs, int Ws, int C, uint8_t* dst, int Hd, int Wd, hipStream_t st);
 void launch_flow_accumulate_finish(const double* acc, const double* wsum, long n, uint8_t* out, hipStream_t st);
 
+// ---- IFNet building blocks (ifnet_ops.hip), used by the whole-model engine in ifnet.hip -------------------------------------
+void launch_ifnet_u8_to_rgb(const uint8_t* in_bgr, int H, int W, int Hp, int Wp, float* out, hipStream_t st);
+void launch_resize_bilinear(const float* src, int Hs, int Ws, int C, float* dst, int Hd, int Wd, int dst_cstride, int dst_coff,
+                            float scale_factor, float mul, hipStream_t st);
+void launch_ifnet_build_x(const float* i0, const float* i1, const float* flow, const float* mask, int H, int W, float timestep,
+                          float* x, hipStream_t st);
+void launch_unshuffle2_cast(DType dt, const void* src, bool src_f32, int h, int w, int C, int src_cstride, void* dst,
+                            int dst_channels, hipStream_t st);
+void launch_depth_to_space4(const float* src, int h, int w, int cs, float* dst, hipStream_t st);
+void launch_ifnet_accumulate(const float* tmp, int hs, int ws, int H, int W, float scale, float* flow, float* mask, int first,
+                             hipStream_t st);
+void launch_ifnet_blend(const float* i0, const float* i1, const float* flow, const float* mask, int Hp, int Wp, int H, int W,
+                        uint8_t* out_bgr, float* out_rgb, hipStream_t st);
+
 // thread-local message returned by fw_last_error()
 std::string& last_error_ref();
 

@@ -240,6 +240,50 @@ __global__ void unsharp_finish_u8_kernel(const uint8_t* __restrict__ src, const 
     }
 }
 
+
+// ---- launchers used by the whole-model engine (ifnet.hip) -------------------------------------------------------------------
+namespace fw {
+static int ifn_grid(long n) { return (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); }
+void launch_ifnet_u8_to_rgb(const uint8_t* in_bgr, int H, int W, int Hp, int Wp, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(u8_to_rgb_f32_kernel, dim3(ifn_grid((long)Hp * Wp)), dim3(256), 0, st, in_bgr, H, W, Hp, Wp, out);
+}
+void launch_resize_bilinear(const float* src, int Hs, int Ws, int C, float* dst, int Hd, int Wd, int dst_cstride, int dst_coff,
+                            float scale_factor, float mul, hipStream_t st) {
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(ifn_grid((long)Hd * Wd)), dim3(256), 0, st, src, Hs, Ws, C, dst, Hd, Wd,
+                       dst_cstride, dst_coff, 1.0f / scale_factor, mul);
+}
+void launch_ifnet_build_x(const float* i0, const float* i1, const float* flow, const float* mask, int H, int W, float timestep,
+                          float* x, hipStream_t st) {
+    hipLaunchKernelGGL(ifnet_build_x_kernel, dim3(ifn_grid((long)H * W)), dim3(256), 0, st, i0, i1, flow, mask, H, W, timestep, x);
+}
+void launch_unshuffle2_cast(DType dt, const void* src, bool src_f32, int h, int w, int C, int src_cstride, void* dst,
+                            int dst_channels, hipStream_t st) {
+    dim3 g(ifn_grid((long)(h / 2) * (w / 2) * dst_channels)), b(256);
+    if (dt == DT_BF16) {
+        if (src_f32)
+            hipLaunchKernelGGL((unshuffle_cast_kernel<__bf16, float>), g, b, 0, st, (const float*)src, h, w, C, src_cstride, (__bf16*)dst, dst_channels);
+        else
+            hipLaunchKernelGGL((unshuffle_cast_kernel<__bf16, __bf16>), g, b, 0, st, (const __bf16*)src, h, w, C, src_cstride, (__bf16*)dst, dst_channels);
+    } else {
+        if (src_f32)
+            hipLaunchKernelGGL((unshuffle_cast_kernel<_Float16, float>), g, b, 0, st, (const float*)src, h, w, C, src_cstride, (_Float16*)dst, dst_channels);
+        else
+            hipLaunchKernelGGL((unshuffle_cast_kernel<_Float16, _Float16>), g, b, 0, st, (const _Float16*)src, h, w, C, src_cstride, (_Float16*)dst, dst_channels);
+    }
+}
+void launch_depth_to_space4(const float* src, int h, int w, int cs, float* dst, hipStream_t st) {
+    hipLaunchKernelGGL(depth_to_space4_kernel, dim3(ifn_grid((long)h * w * 96)), dim3(256), 0, st, src, h, w, cs, dst);
+}
+void launch_ifnet_accumulate(const float* tmp, int hs, int ws, int H, int W, float scale, float* flow, float* mask, int first,
+                             hipStream_t st) {
+    hipLaunchKernelGGL(ifnet_accumulate_kernel, dim3(ifn_grid((long)H * W)), dim3(256), 0, st, tmp, hs, ws, H, W, scale, flow, mask, first);
+}
+void launch_ifnet_blend(const float* i0, const float* i1, const float* flow, const float* mask, int Hp, int Wp, int H, int W,
+                        uint8_t* out_bgr, float* out_rgb, hipStream_t st) {
+    hipLaunchKernelGGL(ifnet_blend_kernel, dim3(ifn_grid((long)H * W)), dim3(256), 0, st, i0, i1, flow, mask, Hp, Wp, H, W, out_bgr, out_rgb);
+}
+}  // namespace fw
+
 using namespace fw;
 
 namespace {

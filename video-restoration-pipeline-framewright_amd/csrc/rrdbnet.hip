@@ -681,6 +681,9 @@ int fw_rrdbnet_profile_read(fw_rrdbnet* n, int* launches, double* total_ms, doub
 
 int fw_rrdbnet_destroy(fw_rrdbnet* n) {
     if (!n) return FW_OK;
+    // a call in flight on another thread finishes first; calling INTO a destroyed handle remains the caller's bug (the Python
+    // engine counts its calls in flight and destroys only when there are none)
+    { std::lock_guard<std::mutex> lk(n->mu); }
     int prev = -1;
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(n->device);

@@ -13,6 +13,7 @@ maps errors to the reference's ``(ok, message)`` convention.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import logging
 import math
@@ -59,6 +60,24 @@ class RRDBNetEngine:
                                                C.byref(h)))
         self._h = h
         self._loaded = False
+        # close() vs. calls in flight: the reference drives one shared upsampler from a thread pool (restorer.py:1830-1973) and
+        # its OOM path clears the cache from whichever worker failed - the handle must not be destroyed under a sibling's call
+        self._cv = threading.Condition()
+        self._in_use = 0
+
+    @contextlib.contextmanager
+    def _handle(self):
+        with self._cv:
+            h = self._h
+            if not h:
+                raise FramewrightHipError(_lib.FW_ERR_INVALID, "RRDBNetEngine: the engine has been closed")
+            self._in_use += 1
+        try:
+            yield h
+        finally:
+            with self._cv:
+                self._in_use -= 1
+                self._cv.notify_all()
 
     # -- weights ------------------------------------------------------------------------------------
     def load_state_dict(self, state: Mapping[str, object]) -> None:
@@ -79,8 +98,10 @@ class RRDBNetEngine:
             if w.shape != (cout, cin, 3, 3) or b.shape != (cout,):
                 raise FramewrightHipError(_lib.FW_ERR_INVALID,
                                           f"{key}: expected weight {(cout, cin, 3, 3)}, got {w.shape}")
-            _lib.check(self._lib.fw_rrdbnet_set_conv(self._h, key.encode(), _np_ptr(w), _np_ptr(b), cout, cin))
-        _lib.check(self._lib.fw_rrdbnet_finalize(self._h))
+            with self._handle() as hd:
+                _lib.check(self._lib.fw_rrdbnet_set_conv(hd, key.encode(), _np_ptr(w), _np_ptr(b), cout, cin))
+        with self._handle() as hd:
+            _lib.check(self._lib.fw_rrdbnet_finalize(hd))
         self._loaded = True
 
     # -- inference ----------------------------------------------------------------------------------
@@ -92,14 +113,16 @@ class RRDBNetEngine:
             f16 = np.ascontiguousarray(frame_bgr)
             h, w = f16.shape[:2]
             out16 = np.empty((h * self.scale, w * self.scale, 3), dtype=np.uint16)
-            _lib.check(self._lib.fw_rrdbnet_upscale_u16(self._h, _np_ptr(f16), _lib.FW_HOST, h, w, _np_ptr(out16),
-                                                        _lib.FW_HOST, None, None))
+            with self._handle() as hd:
+                _lib.check(self._lib.fw_rrdbnet_upscale_u16(hd, _np_ptr(f16), _lib.FW_HOST, h, w, _np_ptr(out16),
+                                                            _lib.FW_HOST, None, None))
             return out16
         frame_bgr = _check_frame(frame_bgr)
         h, w = frame_bgr.shape[:2]
         out = np.empty((h * self.scale, w * self.scale, 3), dtype=np.uint8)
-        _lib.check(self._lib.fw_rrdbnet_upscale_u8(self._h, _np_ptr(frame_bgr), _lib.FW_HOST, h, w, _np_ptr(out),
-                                                   _lib.FW_HOST, None, None))
+        with self._handle() as hd:
+            _lib.check(self._lib.fw_rrdbnet_upscale_u8(hd, _np_ptr(frame_bgr), _lib.FW_HOST, h, w, _np_ptr(out),
+                                                       _lib.FW_HOST, None, None))
         return out
 
     def upscale_device(self, frame_bgr, out=None, out_rgb_f32=None, stream: Optional[int] = None):
@@ -123,10 +146,11 @@ class RRDBNetEngine:
                 raise ValueError("output tensor has the wrong dtype/shape/device")
         if stream is None:
             stream = torch.cuda.current_stream(frame_bgr.device).cuda_stream
-        _lib.check(self._lib.fw_rrdbnet_upscale_u8(
-            self._h, C.c_void_p(frame_bgr.data_ptr()), _lib.FW_DEVICE, h, w,
-            C.c_void_p(out.data_ptr()) if out is not None else None, _lib.FW_DEVICE,
-            C.c_void_p(out_rgb_f32.data_ptr()) if out_rgb_f32 is not None else None, C.c_void_p(stream)))
+        with self._handle() as hd:
+            _lib.check(self._lib.fw_rrdbnet_upscale_u8(
+                hd, C.c_void_p(frame_bgr.data_ptr()), _lib.FW_DEVICE, h, w,
+                C.c_void_p(out.data_ptr()) if out is not None else None, _lib.FW_DEVICE,
+                C.c_void_p(out_rgb_f32.data_ptr()) if out_rgb_f32 is not None else None, C.c_void_p(stream)))
         return out if out is not None else out_rgb_f32
 
     def upscale_stream(self, frames, depth: int = 2):
@@ -193,21 +217,32 @@ class RRDBNetEngine:
 
     # -- introspection ------------------------------------------------------------------------------
     def flops(self, height: int, width: int) -> float:
-        return float(self._lib.fw_rrdbnet_flops(self._h, height, width))
+        with self._handle() as hd:
+            return float(self._lib.fw_rrdbnet_flops(hd, height, width))
 
     def workspace_bytes(self, height: int, width: int) -> int:
-        return int(self._lib.fw_rrdbnet_workspace_bytes(self._h, height, width))
+        with self._handle() as hd:
+            return int(self._lib.fw_rrdbnet_workspace_bytes(hd, height, width))
 
     def profile_enable(self, on: bool) -> None:
-        _lib.check(self._lib.fw_rrdbnet_profile_enable(self._h, 1 if on else 0))
+        with self._handle() as hd:
+            _lib.check(self._lib.fw_rrdbnet_profile_enable(hd, 1 if on else 0))
 
     def profile_read(self) -> Tuple[int, float, float]:
         n, ms, fl = C.c_int(), C.c_double(), C.c_double()
-        _lib.check(self._lib.fw_rrdbnet_profile_read(self._h, C.byref(n), C.byref(ms), C.byref(fl)))
+        with self._handle() as hd:
+            _lib.check(self._lib.fw_rrdbnet_profile_read(hd, C.byref(n), C.byref(ms), C.byref(fl)))
         return n.value, ms.value, fl.value
 
     def close(self) -> None:
-        h, self._h = getattr(self, "_h", None), None
+        """Destroys the native engine once no call is inside it; calls that arrive afterwards raise."""
+        cv = getattr(self, "_cv", None)
+        if cv is None:
+            return
+        with cv:
+            h, self._h = self._h, None
+            while h and self._in_use:
+                cv.wait()
         if h:
             self._lib.fw_rrdbnet_destroy(h)
 
@@ -406,7 +441,8 @@ def get_upsampler(config: PyTorchESRGANConfig) -> HipRealESRGANer:
             up = HipRealESRGANer(netscale, engine, tile, config.tile_pad, config.pre_pad, config.half_precision,
                                  config.gpu_id)
             _UPSAMPLERS[key] = up
-        up.tile_size, up.tile_pad, up.pre_pad = tile, config.tile_pad, config.pre_pad
+        with up._mu:   # enhance() reads them under the same lock
+            up.tile_size, up.tile_pad, up.pre_pad = tile, config.tile_pad, config.pre_pad
         return up
 
 
@@ -474,7 +510,8 @@ def clear_upsampler_cache() -> None:
         ups = list(_UPSAMPLERS.values())
         _UPSAMPLERS.clear()
     for up in ups:
-        up.engine.close()
+        with up._mu:            # a sibling worker's enhance() in flight finishes first (restorer.py:1830-1973 thread pool)
+            up.engine.close()
 
 
 NCNN_TO_PYTORCH_MODEL = {

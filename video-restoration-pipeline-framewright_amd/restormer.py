@@ -192,6 +192,7 @@ class RestormerEngine:
         self._w = W
 
     # ---- forward ----------------------------------------------------------------------------------------------------
+    @_lib.on_tensor_device
     def denoise_device(self, frame, out=None, out_rgb_f32=None):
         """torch.uint8 CUDA tensor H x W x 3 (H, W multiples of 8, as the network's three PixelUnshuffles require) -> same
         shape; asynchronous on torch's current stream."""

@@ -24,7 +24,7 @@ import numpy as np
 from . import _lib, policy
 from ._lib import FramewrightHipError
 from .realesrgan import _imread, _imwrite, _to_numpy
-from .synth import IFNET_CHANNELS, IFNET_SCALES, ifnet_tensor_shapes
+from .synth import ifnet_tensor_shapes
 
 logger = logging.getLogger(__name__)
 
@@ -69,165 +69,90 @@ def convtranspose_as_3x3(w: np.ndarray, b: np.ndarray) -> Tuple[np.ndarray, np.n
     return out, np.repeat(b.astype(np.float32), 4)
 
 
-@dataclass
-class _Group:
-    w: object          # packed weights (torch int16 CUDA)
-    b: object          # fp32 bias padded to 32*ct
-    ct: int
-    off: int           # first output channel
-
-
-class _Conv:
-    """One 3x3 convolution split into launches of <= 64 output channels."""
-
-    def __init__(self, lib, dtype_id: int, w: np.ndarray, b: np.ndarray, cin_pad: int, cout_pad: int, device, pairs_only: bool):
-        import torch
-        cout, cin = w.shape[:2]
-        wp = np.zeros((cout_pad, cin_pad, 3, 3), np.float32)
-        wp[:cout, :cin] = w
-        bp = np.zeros((cout_pad,), np.float32)
-        bp[:cout] = b
-        self.cin_pad, self.cout_pad = cin_pad, cout_pad
-        self.groups: List[_Group] = []
-        off = 0
-        while off < cout_pad:
-            ct = 2 if cout_pad - off >= 64 else 1
-            if pairs_only and ct != 2:
-                raise ValueError("residual convolutions need output channels in multiples of 64")
-            sl = np.ascontiguousarray(wp[off:off + 32 * ct])
-            n = lib.fw_pack_conv3x3(dtype_id, None, 32 * ct, cin_pad, ct, cin_pad // 32, None)
-            buf = np.zeros(n, np.uint16)
-            lib.fw_pack_conv3x3(dtype_id, C.c_void_p(sl.ctypes.data), 32 * ct, cin_pad, ct, cin_pad // 32,
-                                C.c_void_p(buf.ctypes.data))
-            self.groups.append(_Group(torch.from_numpy(buf.view(np.int16)).to(device),
-                                      torch.from_numpy(np.ascontiguousarray(bp[off:off + 32 * ct])).to(device), ct, off))
-            off += 32 * ct
-
-
 class IFNetEngine:
-    """IFNet v4.6 resident on one GPU."""
+    """IFNet v4.6 resident on one GPU: thin owner of an ``fw_ifnet*`` (csrc/ifnet.hip).  The weight transforms, the workspace
+    and the ~100 launches of a forward live behind the C-ABI (``fw_ifnet_interp_u8``), serialised per handle by its mutex;
+    ``stride2_as_unshuffled_3x3`` / ``convtranspose_as_3x3`` above are the numpy statements of the two transforms the C++
+    side applies (tests check both against torch convolutions)."""
 
     def __init__(self, dtype: str = "f16", device_id: int = 0):
         import torch
         self._lib = _lib.load()
         _lib.require_gpu()
+        if dtype not in _lib.DTYPES:
+            raise ValueError(f"dtype must be one of {sorted(_lib.DTYPES)}")
         self.dtype, self.device_id = dtype, int(device_id)
-        self._dt = _lib.DTYPES[dtype]
-        self._tdt = torch.float16 if self._dt == _lib.FW_DTYPE_F16 else torch.bfloat16
         self._dev = torch.device("cuda", self.device_id)
-        self._blocks: List[Dict[str, object]] = []
+        h = C.c_void_p()
+        _lib.check(self._lib.fw_ifnet_create(self.device_id, _lib.DTYPES[dtype], C.byref(h)))
+        self._h = h
+        self._loaded = False
 
     def load_state_dict(self, state: Mapping[str, object]) -> None:
-        import torch
-        sd = {}
         for key, shape in ifnet_tensor_shapes():
             if key not in state:
                 raise FramewrightHipError(_lib.FW_ERR_INVALID, f"state dict is missing {key}")
             a = np.ascontiguousarray(_to_numpy(state[key]), dtype=np.float32)
             if tuple(a.shape) != tuple(shape):
                 raise FramewrightHipError(_lib.FW_ERR_INVALID, f"{key}: expected shape {shape}, got {a.shape}")
-            sd[key] = a
-        self._blocks = []
-        for i, c in enumerate(IFNET_CHANNELS):
-            p = f"block{i}."
-            cin = 7 if i == 0 else 12
-            c2p, cp = _pad(c // 2, 32), _pad(c, 64)
-            blk: Dict[str, object] = {"c": c, "cin": cin, "c2p": c2p, "cp": cp}
-            blk["conv0_0"] = _Conv(self._lib, self._dt, stride2_as_unshuffled_3x3(sd[p + "conv0.0.0.weight"]),
-                                   sd[p + "conv0.0.0.bias"], _pad(4 * cin, 32), c2p, self._dev, False)
-            w1 = np.zeros((c, c2p, 3, 3), np.float32)
-            w1[:, :c // 2] = sd[p + "conv0.1.0.weight"]
-            blk["conv0_1"] = _Conv(self._lib, self._dt, stride2_as_unshuffled_3x3(w1), sd[p + "conv0.1.0.bias"], 4 * c2p, cp,
-                                   self._dev, False)
-            res = []
-            for j in range(8):
-                q = f"{p}convblock.{j}."
-                beta = np.zeros((cp,), np.float32)
-                beta[:c] = sd[q + "beta"].reshape(-1)
-                res.append((_Conv(self._lib, self._dt, sd[q + "conv.weight"], sd[q + "conv.bias"], cp, cp, self._dev, True),
-                            torch.from_numpy(beta).to(self._dev)))
-            blk["res"] = res
-            w3, b3 = convtranspose_as_3x3(sd[p + "lastconv.0.weight"], sd[p + "lastconv.0.bias"])
-            blk["last"] = _Conv(self._lib, self._dt, w3, b3, cp, 96, self._dev, False)
-            self._blocks.append(blk)
+            _lib.check(self._lib.fw_ifnet_set_tensor(self._h, key.encode(), C.c_void_p(a.ctypes.data), a.size))
+        _lib.check(self._lib.fw_ifnet_finalize(self._h))
+        self._loaded = True
 
-    # -- launch helpers ---------------------------------------------------------------------------------------
-    def _conv(self, conv: _Conv, x, h: int, w: int, st, out=None, out_f32=None, act=0, res=None, beta=None, post_act=0):
-        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-        for g in conv.groups:
-            _lib.check(self._lib.fw_conv3x3_nhwc_ex(
-                self._dt, p(x), conv.cin_pad, 0, conv.cin_pad // 32, h, w, p(g.w), p(g.b), g.ct, act, 0,
-                p(res), 1.0, None, 1.0, C.c_void_p(beta.data_ptr() + 4 * g.off) if beta is not None else None, post_act,
-                conv.cout_pad, g.off, p(out), conv.cout_pad, 0, g.off, p(out_f32), st))
+    def flops(self, height: int, width: int) -> float:
+        return float(self._lib.fw_ifnet_flops(self._h, height, width))
 
     def interpolate_device(self, img0, img1, timestep: float = 0.5, out=None, out_rgb_f32=None):
-        """img0/img1: uint8 CUDA tensors H x W x 3 (BGR).  Returns the uint8 mid frame (asynchronous on torch's current
-        stream)."""
+        """img0/img1: uint8 CUDA tensors H x W x 3 (BGR) on the engine's device.  Returns the uint8 mid frame (asynchronous on
+        torch's current stream of that device)."""
         import torch
-        if not self._blocks:
+        if not self._loaded:
             raise FramewrightHipError(_lib.FW_ERR_INVALID, "IFNetEngine: no weights loaded")
         for t in (img0, img1):
             if t.dtype != torch.uint8 or not t.is_cuda or t.dim() != 3 or t.shape[2] != 3 or not t.is_contiguous():
                 raise ValueError("interpolate_device expects contiguous uint8 CUDA tensors H x W x 3")
         if img0.shape != img1.shape:
             raise ValueError("frame sizes differ")
-        lib, dev = self._lib, img0.device
+        if img0.device != self._dev or img1.device != self._dev:
+            raise ValueError(f"tensors are on {img0.device} / {img1.device}, engine on {self._dev}")
         H, W = int(img0.shape[0]), int(img0.shape[1])
-        Hp, Wp = _pad(H, 32), _pad(W, 32)
-        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-        f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-        typ = lambda *s: torch.empty(s, dtype=self._tdt, device=dev)
-        I0, I1 = f32(Hp, Wp, 3), f32(Hp, Wp, 3)
-        _lib.check(lib.fw_u8_to_rgb_f32(p(img0), H, W, Hp, Wp, p(I0), st))
-        _lib.check(lib.fw_u8_to_rgb_f32(p(img1), H, W, Hp, Wp, p(I1), st))
-        flow, mask = f32(Hp, Wp, 4), f32(Hp, Wp, 1)
-        for i, (blk, s) in enumerate(zip(self._blocks, IFNET_SCALES)):
-            first = i == 0
-            cin, c2p, cp = blk["cin"], blk["c2p"], blk["cp"]
-            X = f32(Hp, Wp, 7 if first else 8)
-            _lib.check(lib.fw_ifnet_build_x(p(I0), p(I1), None if first else p(flow), None if first else p(mask), Hp, Wp,
-                                            float(timestep), p(X), st))
-            hs, ws = Hp // s, Wp // s
-            xin = f32(hs, ws, cin)
-            _lib.check(lib.fw_resize_bilinear_f32(p(X), Hp, Wp, X.shape[2], p(xin), hs, ws, cin, 0, 1.0 / s, 1.0, st))
-            if not first:
-                _lib.check(lib.fw_resize_bilinear_f32(p(flow), Hp, Wp, 4, p(xin), hs, ws, cin, 8, 1.0 / s, 1.0 / s, st))
-            # conv0: two stride-2 convs (+LeakyReLU) as 3x3 convs on pixel-unshuffled tensors
-            c00, c01 = blk["conv0_0"], blk["conv0_1"]
-            u0 = typ(hs // 2, ws // 2, c00.cin_pad)
-            _lib.check(lib.fw_unshuffle2_cast(self._dt, p(xin), 1, hs, ws, cin, cin, p(u0), c00.cin_pad, st))
-            a0 = typ(hs // 2, ws // 2, c2p)
-            self._conv(c00, u0, hs // 2, ws // 2, st, out=a0, act=1)
-            u1 = typ(hs // 4, ws // 4, c01.cin_pad)
-            _lib.check(lib.fw_unshuffle2_cast(self._dt, p(a0), 0, hs // 2, ws // 2, c2p, c2p, p(u1), c01.cin_pad, st))
-            hf, wf = hs // 4, ws // 4
-            feat, feat32 = typ(hf, wf, cp), f32(hf, wf, cp)
-            self._conv(c01, u1, hf, wf, st, out=feat, out_f32=feat32, act=1)
-            nxt, nxt32 = typ(hf, wf, cp), f32(hf, wf, cp)
-            for conv, beta in blk["res"]:   # ResConv: lrelu(conv(x) * beta + x)
-                self._conv(conv, feat, hf, wf, st, out=nxt, out_f32=nxt32, res=feat32, beta=beta, post_act=1)
-                feat, nxt = nxt, feat
-                feat32, nxt32 = nxt32, feat32
-            # lastconv: ConvTranspose2d(c, 24, 4, 2, 1) + PixelShuffle(2) -> 6 channels at (hs, ws)
-            t96 = f32(hf, wf, 96)
-            self._conv(blk["last"], feat, hf, wf, st, out_f32=t96)
-            tmp = f32(hs, ws, 6)
-            _lib.check(lib.fw_depth_to_space4_f32(p(t96), hf, wf, 96, p(tmp), st))
-            _lib.check(lib.fw_ifnet_accumulate(p(tmp), hs, ws, Hp, Wp, float(s), p(flow), p(mask), 1 if first else 0, st))
         if out is None and out_rgb_f32 is None:
-            out = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
-        _lib.check(lib.fw_ifnet_blend(p(I0), p(I1), p(flow), p(mask), Hp, Wp, H, W, p(out), p(out_rgb_f32), st))
-        self._last_flow = flow
+            out = torch.empty((H, W, 3), dtype=torch.uint8, device=self._dev)
+        for t, dt in ((out, torch.uint8), (out_rgb_f32, torch.float32)):
+            if t is not None and (t.dtype != dt or tuple(t.shape) != (H, W, 3) or not t.is_contiguous() or t.device != self._dev):
+                raise ValueError("output tensor has the wrong dtype/shape/device")
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        st = C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)
+        _lib.check(self._lib.fw_ifnet_interp_u8(self._h, p(img0), p(img1), _lib.FW_DEVICE, H, W, float(timestep), p(out),
+                                                _lib.FW_DEVICE, p(out_rgb_f32), st))
         return out if out is not None else out_rgb_f32
 
     def interpolate(self, img0: np.ndarray, img1: np.ndarray, timestep: float = 0.5) -> np.ndarray:
-        import torch
-        a = torch.from_numpy(np.ascontiguousarray(img0)).to(self._dev)
-        b = torch.from_numpy(np.ascontiguousarray(img1)).to(self._dev)
-        out = self.interpolate_device(a, b, timestep)
-        torch.cuda.synchronize(self._dev)
-        return out.cpu().numpy()
+        """Host frames in, host frame out (the engine stages them: ``FW_HOST`` buffers through the C-ABI)."""
+        if not self._loaded:
+            raise FramewrightHipError(_lib.FW_ERR_INVALID, "IFNetEngine: no weights loaded")
+        a, b = np.ascontiguousarray(img0), np.ascontiguousarray(img1)
+        for f in (a, b):
+            if f.dtype != np.uint8 or f.ndim != 3 or f.shape[2] != 3:
+                raise ValueError("expected H x W x 3 uint8 BGR frames")
+        if a.shape != b.shape:
+            raise ValueError("frame sizes differ")
+        out = np.empty_like(a)
+        _lib.check(self._lib.fw_ifnet_interp_u8(self._h, C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), _lib.FW_HOST,
+                                                a.shape[0], a.shape[1], float(timestep), C.c_void_p(out.ctypes.data), _lib.FW_HOST,
+                                                None, None))
+        return out
+
+    def close(self) -> None:
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.fw_ifnet_destroy(h)
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---- directory-level driver (FrameInterpolator) ---------------------------------------------------------------------
@@ -368,6 +293,7 @@ class FrameInterpolator:
         return bounds
 
     # -- motion-blur reduction (interpolation.py:403-486) -------------------------------------------------------------------
+    @_lib.on_tensor_device
     def apply_motion_blur_reduction_device(self, frame, strength: float = 1.0):
         """uint8 CUDA tensor H x W x C -> sharpened tensor: Pillow's UnsharpMask(2, int(100 s), 3) and, above s = 1.5, a second
         UnsharpMask(1, int(50 s), 2), bit for bit (fw_unsharp_mask_u8)."""

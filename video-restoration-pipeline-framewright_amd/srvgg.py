@@ -128,6 +128,7 @@ class SRVGGNetEngine:
         mac = 9.0 * (3 * NUM_FEAT + self.num_conv * NUM_FEAT * NUM_FEAT + NUM_FEAT * 3 * self.scale ** 2)
         return 2.0 * mac * H * W
 
+    @_lib.on_tensor_device
     def upscale_device(self, frame_bgr, out=None, out_rgb_f32=None):
         """frame_bgr: uint8 CUDA tensor H x W x 3.  Returns the uint8 BGR result (asynchronous on torch's current stream)."""
         import torch

@@ -138,6 +138,7 @@ class NAFNetEngine:
                                                   C.c_void_p(out.ctypes.data), _lib.FW_HOST, None, None))
         return out
 
+    @_lib.on_tensor_device
     def denoise_device(self, frame, out=None, out_rgb_f32=None, stream: Optional[int] = None):
         """torch.uint8 CUDA tensor H x W x 3 -> same shape; asynchronous on torch's current stream."""
         import torch
@@ -246,9 +247,11 @@ class TAPDenoiser:
 
     # -- device helpers --------------------------------------------------------------------------------
     def _stream(self):
+        # every caller runs under on_tensor_device: the current device is the one that owns the frames
         import torch
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return C.c_void_p(torch.cuda.current_stream(torch.cuda.current_device()).cuda_stream)
 
+    @_lib.on_tensor_device
     def _denoise_frame_tiled_device(self, frame):
         """tap_denoise.py:417-488 on a uint8 CUDA tensor; returns a uint8 CUDA tensor."""
         import torch
@@ -322,6 +325,7 @@ class TAPDenoiser:
         wk["free"] = torch.cuda.Event()
         wk["free"].record(main)      # the worker may overwrite its tile buffers after this point
 
+    @_lib.on_tensor_device
     def _temporal_average_device(self, denoised: Sequence, weights: Sequence[float]):
         import torch
         lib = _lib.load()
@@ -332,6 +336,7 @@ class TAPDenoiser:
         _lib.check(lib.fw_temporal_average_u8(ptrs, ws, k, denoised[0].numel(), C.c_void_p(out.data_ptr()), self._stream()))
         return out
 
+    @_lib.on_tensor_device
     def _strength_blend_device(self, original, denoised):
         import torch
         out = torch.empty_like(original)
@@ -340,6 +345,7 @@ class TAPDenoiser:
                                                     C.c_void_p(out.data_ptr()), self._stream()))
         return out
 
+    @_lib.on_tensor_device
     def _grain_addback_device(self, original, denoised, factor: float = 0.3):
         """preserve_grain (tap_denoise.py:621-632): high-pass of the original's gray image added back, on the device."""
         import torch
@@ -368,10 +374,13 @@ class TAPDenoiser:
         out = self.denoise_clip_device(frames, only=only, halo_before=halo_before, halo_after=halo_after)
         return [None if d is None else d.cpu().numpy() for d in out]
 
+    @_lib.on_tensor_device
     def denoise_clip_device(self, frames: Sequence, only: Optional[Sequence[int]] = None, halo_before: Sequence = (),
-                            halo_after: Sequence = ()) -> List:
+                            halo_after: Sequence = (), denoised: Optional[Sequence] = None) -> List:
         """``denoise_clip`` with the results left in HBM (uint8 CUDA tensors): the stage hand-off of SURVEY.md §8(f) item 1.
-        ``frames`` / halos may be numpy arrays (uploaded on first use) or uint8 CUDA tensors."""
+        ``frames`` / halos may be numpy arrays (uploaded on first use) or uint8 CUDA tensors.  ``denoised[i]`` (optional) is
+        frame i already through the network (``denoise_only_device``): the multi-GPU path denoises a block once, ships its
+        edge frames to the neighbours and then runs the windows here without a second forward."""
         import torch
         self._load_model()
         dev = torch.device("cuda", self.config.gpu_id)
@@ -390,6 +399,8 @@ class TAPDenoiser:
                     cache[i] = up(halo_before[hb + i])
                 elif i >= n:
                     cache[i] = up(halo_after[i - n])
+                elif denoised is not None and denoised[i] is not None:
+                    cache[i] = denoised[i]
                 else:
                     cache[i] = self._denoise_frame_tiled_device(up(frames[i]))
             return cache[i]
@@ -416,6 +427,13 @@ class TAPDenoiser:
             for j in [k for k in cache if k < i - half]:  # frames that no later window needs
                 del cache[j]
         return out
+
+    @_lib.on_tensor_device
+    def denoise_only_device(self, frames: Sequence) -> List:
+        """Every frame (uint8 CUDA tensors) through the network with the configured tiling, no temporal window: what a rank
+        computes once per owned frame before the halo exchange."""
+        self._load_model()
+        return [self._denoise_frame_tiled_device(f.contiguous()) for f in frames]
 
     def denoise_halo_frames(self, frames: Sequence[np.ndarray], count: int, head: bool) -> List[np.ndarray]:
         """The first/last ``count`` frames of this rank's block, denoised (tiled) but not yet temporally averaged —

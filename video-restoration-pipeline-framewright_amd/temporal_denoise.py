@@ -60,6 +60,7 @@ class DeviceTemporalAccumulator:
         self._accumulate(torch.from_numpy(np.ascontiguousarray(frame)).to(dev), flow, 1.0, None, None, inverse, acc, ws)
         return self._finish(acc, ws)
 
+    @_lib.on_tensor_device
     def _accumulate(self, frame_dev, flow: Optional[FlowField], scale: float, wmap, thr, inverse, acc, ws) -> None:
         import torch
         dev = acc.device
@@ -82,6 +83,7 @@ class DeviceTemporalAccumulator:
                                                    float(thr) if thr is not None else 0.0, int(bool(inverse)), h, w, p(acc), p(ws), st))
         torch.cuda.current_stream(dev).synchronize()   # the uploaded maps above are temporaries
 
+    @_lib.on_tensor_device
     def _finish(self, acc, ws) -> np.ndarray:
         import torch
         h, w = int(acc.shape[0]), int(acc.shape[1])
