@@ -399,6 +399,24 @@ size_t fw_ifnet_workspace_bytes(const fw_ifnet* net, int height, int width);
 double fw_ifnet_flops(const fw_ifnet* net, int height, int width);
 int fw_ifnet_destroy(fw_ifnet* net);
 
+/* ---- Restormer (the reference's default TAP model) as one engine ---------------------------------------------------------------
+ * Replaces `basicsr.archs.restormer_arch.Restormer(inp_channels=3, out_channels=3, dim=48, num_blocks=[4,6,6,8],
+ * num_refinement_blocks=4, heads=[1,2,4,8], ffn_expansion_factor=2.66, bias=False, LayerNorm_type='WithBias')` as constructed
+ * and called at reference src/framewright/processors/tap_denoise.py:299-333 and :458, together with the pre / post-processing of
+ * :373-415 (BGR uint8 in, `np.clip(x * 255, 0, 255).astype(uint8)` out - truncation).  Same life cycle as fw_nafnet: create,
+ * set every tensor of the state dict (fp32, PyTorch layouts and key names), finalize, denoise.  One handle per GPU, calls
+ * serialised by an internal mutex; the workspace is one arena sized by a dry run of the launch sequence. */
+typedef struct fw_restormer fw_restormer;
+int fw_restormer_create(int device_id, int dim, const int* num_blocks /* [4] */, int num_refinement_blocks,
+                        const int* heads /* [4] */, double ffn_expansion_factor, int dtype, fw_restormer** out);
+int fw_restormer_set_tensor(fw_restormer* net, const char* key, const float* data, size_t numel);
+int fw_restormer_finalize(fw_restormer* net);
+/* in_bgr / out_bgr: uint8 BGR H x W x 3, H and W multiples of 8; out_rgb_f32 (device, optional): the un-quantised RGB output. */
+int fw_restormer_denoise_u8(fw_restormer* net, const uint8_t* in_bgr, int in_loc, int height, int width, uint8_t* out_bgr,
+                            int out_loc, float* out_rgb_f32, void* stream);
+size_t fw_restormer_workspace_bytes(fw_restormer* net, int height, int width);   /* 0 before finalize */
+int fw_restormer_destroy(fw_restormer* net);
+
 #ifdef __cplusplus
 }
 #endif

@@ -324,6 +324,8 @@ def interfaces() -> None:
         "framewright.infrastructure.gpu.backends.base": ["Backend", "BackendCapabilities"],
         "framewright.processors.temporal_denoise": ["FlowField"],
         "framewright.processors.interpolation": ["InterpolationConfig", "FrameInterpolator"],
+        "framewright.infrastructure.gpu.distributor": ["GPUStats", "DistributionPlan", "ProcessingResult", "GPUDistributor",
+                                                       "MultiGPUProcessor"],
     }
     out, failed = {}, {}
     for mod, names in wanted.items():
@@ -450,6 +452,58 @@ def interpolator_logic() -> None:
     print("wrote tests/golden/interpolator_reference.{npz,json}; scene boundaries", bounds, "skimage", ip.HAS_SKIMAGE)
 
 
+def gpu_distributor_logic() -> None:
+    """Fixture set 9 - the five planners of infrastructure/gpu/distributor.py (:287-490) and ``get_optimal_distribution``
+    (:472-507) evaluated by the reference's own ``GPUDistributor`` on hand-made device tables (its detector is bypassed by
+    filling ``_devices`` / ``_stats``, the attributes its planners read).  -> tests/golden/gpu_distributor_reference.json"""
+    import json
+    d = load_reference("framewright.infrastructure.gpu.distributor")
+    det = load_reference("framewright.infrastructure.gpu.detector")
+    tables = {
+        "one": [(0, 294912, 280000)],
+        "eight_equal": [(i, 294912, 290000) for i in range(8)],
+        "mixed": [(0, 24576, 20000), (1, 8192, 1000), (2, 16384, 16000)],
+        "one_full": [(0, 294912, 0), (1, 294912, 100000)],
+        "all_full": [(0, 8192, 0), (1, 4096, 0)],
+    }
+    timings = {"none": {}, "measured": {0: (12, 0.071), 1: (15, 0.140), 2: (11, 0.05)}, "few": {0: (3, 0.2)}}
+    cases = []
+    for tname, table in tables.items():
+        for sname, tm in timings.items():
+            for n in (0, 1, 7, 100, 301):
+                gd = d.GPUDistributor()
+                gd._devices = [det.DeviceInfo(index=i, name=f"gpu{i}", vendor=det.GPUVendor.AMD, total_memory_mb=t, free_memory_mb=f)
+                               for i, t, f in table]
+                for dev in gd._devices:
+                    st = d.GPUStats(device_id=dev.index, vendor=dev.vendor, name=dev.name, total_memory_mb=dev.total_memory_mb)
+                    if dev.index in tm:
+                        cnt, avg = tm[dev.index]
+                        st.frames_processed, st.avg_time_per_frame, st.total_time_seconds = cnt, avg, cnt * avg
+                    gd._stats[dev.index] = st
+                row = {"table": tname, "devices": table, "timing": sname, "stats": {str(k): list(v) for k, v in tm.items()}, "n": n, "plans": {}}
+                for strat in d.DistributionStrategy:
+                    try:
+                        plan = gd.distribute_frames(n, strat)
+                        row["plans"][strat.value] = {str(k): v for k, v in plan.gpu_workloads.items()}
+                    except Exception as e:  # noqa: BLE001 - e.g. ZeroDivisionError of the load-balanced planner when no device has free memory
+                        row["plans"][strat.value] = {"error": type(e).__name__}
+                try:
+                    opt = gd.get_optimal_distribution(n)
+                    row["optimal"] = {str(k): v for k, v in opt.gpu_workloads.items()}
+                except Exception as e:  # noqa: BLE001
+                    row["optimal"] = {"error": type(e).__name__}
+                cases.append(row)
+    # unhealthy devices are skipped by distribute_frames (:262-270)
+    gd = d.GPUDistributor(d.DistributionStrategy.ROUND_ROBIN)
+    gd._devices = [det.DeviceInfo(index=i, name=f"gpu{i}", vendor=det.GPUVendor.AMD, total_memory_mb=1000, free_memory_mb=900) for i in range(3)]
+    for dev in gd._devices:
+        gd._stats[dev.index] = d.GPUStats(device_id=dev.index, vendor=dev.vendor, name=dev.name)
+    gd.mark_device_unhealthy(1)
+    unhealthy = {str(k): v for k, v in gd.distribute_frames(6).gpu_workloads.items()}
+    (ROOT / "tests" / "golden" / "gpu_distributor_reference.json").write_text(json.dumps({"cases": cases, "unhealthy_rr": unhealthy}))
+    print("wrote tests/golden/gpu_distributor_reference.json;", len(cases), "cases")
+
+
 def assign_frames_logic() -> None:
     """Fixture set 6 - `MultiGPUDistributor._assign_frames` (utils/multi_gpu.py:780-870) evaluated by the reference itself for
     every LoadBalanceStrategy on synthetic GPUInfo lists.  -> tests/golden/assign_frames.json"""
@@ -486,3 +540,4 @@ if __name__ == "__main__":
     assign_frames_logic()
     aesrgan_attention()
     interpolator_logic()
+    gpu_distributor_logic()

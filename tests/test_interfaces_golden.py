@@ -11,6 +11,7 @@ from pathlib import Path
 import pytest
 
 from framewright_amd import backends as B
+from framewright_amd import gpu_distributor as GD
 from framewright_amd import plugins as PL
 from framewright_amd import realesrgan as R
 from framewright_amd import rife as RF
@@ -38,6 +39,11 @@ MIRRORS = {
     "temporal_denoise.FlowField": TD.FlowField,
     "interpolation.InterpolationConfig": RF.InterpolationConfig,
     "interpolation.FrameInterpolator": RF.FrameInterpolator,
+    "distributor.GPUStats": GD.GPUStats,
+    "distributor.DistributionPlan": GD.DistributionPlan,
+    "distributor.ProcessingResult": GD.ProcessingResult,
+    "distributor.GPUDistributor": GD.GPUDistributor,
+    "distributor.MultiGPUProcessor": GD.MultiGPUProcessor,
 }
 
 

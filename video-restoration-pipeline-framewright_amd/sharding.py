@@ -163,7 +163,7 @@ def sharded_pairs(frames: Sequence, interp_pair: Callable, device="cpu") -> Dict
     return out
 
 
-def sharded_tap_denoise_device(tap, frames: Sequence) -> Dict[int, object]:
+def sharded_tap_denoise_device(tap, frames: Sequence, halo_device=None) -> Dict[int, object]:
     """BASELINE configs[3] on the real engine, device-resident: this rank's block of ``frames`` (numpy arrays or uint8 CUDA
     tensors; entries outside the block may be None) through ``tap`` (a TAPDenoiser).  Every frame is denoised ONCE by the rank
     that owns it; the first / last ``temporal_window // 2`` denoised frames go to the neighbours as CUDA tensors (ncclSend /
@@ -183,9 +183,12 @@ def sharded_tap_denoise_device(tap, frames: Sequence) -> Dict[int, object]:
     prev_halo = next_halo = None
     if world > 1 and radius > 0:
         shape = tuple(den[0].shape)
+        hd = dev if halo_device is None else torch.device(halo_device)
         prev_halo, next_halo = exchange_with_neighbours(
-            torch.stack(den[:sp]) if sp else None, torch.stack(den[-sn:]) if sn else None,
-            (rp,) + shape if rp else None, (rn,) + shape if rn else None, dev)
+            torch.stack(den[:sp]).to(hd) if sp else None, torch.stack(den[-sn:]).to(hd) if sn else None,
+            (rp,) + shape if rp else None, (rn,) + shape if rn else None, hd)
+        prev_halo = prev_halo.to(dev) if prev_halo is not None else None
+        next_halo = next_halo.to(dev) if next_halo is not None else None
     out = tap.denoise_clip_device(block, halo_before=[prev_halo[j] for j in range(rp)] if prev_halo is not None else (),
                                   halo_after=[next_halo[j] for j in range(rn)] if next_halo is not None else (), denoised=den)
     return {lo + j: o for j, o in enumerate(out)}
