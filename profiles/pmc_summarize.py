@@ -4,7 +4,7 @@ import collections, csv, glob, json, sys
 d = sys.argv[1]
 out = {}
 for p in sorted(glob.glob(f"{d}/p*")):
-    f = glob.glob(f"{p}/runc/*_counter_collection.csv")
+    f = glob.glob(f"{p}/**/*_counter_collection.csv", recursive=True)
     if not f:
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(float))

@@ -1,20 +1,27 @@
 #!/bin/bash
-# Regenerates the judged profile artefacts on the GPU box (run from the repo root through gpurun):
-#   gpurun_out/pmc/p1,p2      FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1 --warmup 1` (separate passes)
-#   gpurun_out/pmc/p3         MFMA-busy / LDS-conflict counters
-#   gpurun_out/r01_traffic.json  per-launch HBM traffic from p1 + p2 (also written to profiles/ so that the bench line
-#                                that follows quotes the traffic of THIS build)
-#   gpurun_out/bench.json     the default bench line
-#   gpurun_out/stats/         rocprofv3 --kernel-trace --stats of `bench.py --steps 5 --warmup 2`
+# Regenerates the judged profile artefacts of round 2 on the GPU box (run from the repo root through gpurun; ~6 min):
+#   gpurun_out/r02/pmc/p1,p2   FETCH_SIZE / WRITE_SIZE passes of the headline bench (separate passes), p3: MFMA-busy / LDS counters
+#   profiles/r02_traffic.json  per-launch and per-frame HBM traffic from p1 + p2, tagged with the library digest (written first,
+#                              so that the bench line that follows quotes the traffic of THIS build)
+#   gpurun_out/r02/bench_{sr,rife,tap,chain}.json   the four bench lines
+#   gpurun_out/r02/stats_{sr,tap,rife,restormer}/   rocprofv3 --kernel-trace --stats summaries
 set -e
 root=$GRAFT_REPO_ROOT
-mkdir -p "$root/gpurun_out"
-bash "$root/profiles/pmc_pass.sh" "$root/gpurun_out/pmc/p1" FETCH_SIZE
-bash "$root/profiles/pmc_pass.sh" "$root/gpurun_out/pmc/p2" WRITE_SIZE
-bash "$root/profiles/pmc_pass.sh" "$root/gpurun_out/pmc/p3" SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY
+o="$root/gpurun_out/r02"
+mkdir -p "$o"
+bash "$root/profiles/pmc_pass.sh" "$o/pmc/p1" FETCH_SIZE
+bash "$root/profiles/pmc_pass.sh" "$o/pmc/p2" WRITE_SIZE
+bash "$root/profiles/pmc_pass.sh" "$o/pmc/p3" SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY
 cd "$root"
-python3 tools/make_traffic.py gpurun_out/pmc profiles/r01_traffic.json > /dev/null
-cp profiles/r01_traffic.json gpurun_out/r01_traffic.json
-python3 bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err
+python3 tools/make_traffic.py "$o/pmc" profiles/r02_traffic.json f16 > /dev/null
+cp profiles/r02_traffic.json "$o/r02_traffic.json"
+python3 profiles/pmc_summarize.py "$o/pmc" "$o/pmc_summary.json" || true
+python3 bench.py > "$o/bench_sr.json" 2> "$o/bench_sr.err"
+python3 bench.py --config rife > "$o/bench_rife.json" 2> "$o/bench_rife.err"
+python3 bench.py --config tap > "$o/bench_tap.json" 2> "$o/bench_tap.err"
+python3 bench.py --config chain > "$o/bench_chain.json" 2> "$o/bench_chain.err"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$root/gpurun_out/stats" -- python3 "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$root/gpurun_out/stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$o/stats_sr" -- python3 "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-host-path > "$o/stats_sr.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$o/stats_tap" -- python3 "$root/tools/profile_nafnet.py" > "$o/stats_tap.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$o/stats_rife" -- python3 "$root/tools/profile_ifnet.py" > "$o/stats_rife.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$o/stats_restormer" -- python3 "$root/tools/profile_restormer.py" > "$o/stats_restormer.log" 2>&1

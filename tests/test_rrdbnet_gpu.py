@@ -413,3 +413,66 @@ def test_sliding_window_pair_kernel_equals_ring_kernel_at_1080p(hip_lib, monkeyp
     assert torch.equal(outs[0], outs[1])
     assert int(outs[0].max()) > int(outs[0].min())          # not a constant image
     eng.close()
+
+
+def test_thread_pool_on_one_shared_upsampler_with_an_injected_oom(hip_lib, tmp_path, monkeypatch):
+    """The reference drives enhance_frame_pytorch from ThreadPoolExecutor(parallel_frames) against ONE shared upsampler
+    (restorer.py:1830-1973, B1 of SURVEY.md section 8(b)): every frame equals the serial result, and an out-of-memory frame on
+    one worker - whose handler clears the upsampler cache (pytorch_realesrgan.py:237-244) - neither crashes the workers that
+    are inside the engine at that moment nor leaves them with a destroyed handle: they finish or report, the next call
+    rebuilds the upsampler."""
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    monkeypatch.setenv("FRAMEWRIGHT_AMD_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("FRAMEWRIGHT_MODEL_DIR", str(tmp_path / "none"))
+    R.clear_upsampler_cache()
+    cfg = R.PyTorchESRGANConfig(model_name="RealESRGAN_x4plus_anime_6B", scale_factor=4)
+    frames = synthetic_frames(12, 36, 52, seed=77)
+    for i, f in enumerate(frames):
+        Image.fromarray(f[:, :, ::-1]).save(tmp_path / f"in_{i:02d}.png")
+    up = R.get_upsampler(cfg)
+    serial = [up.enhance(f, outscale=4)[0] for f in frames]
+
+    # (1) one handle, many threads through .enhance
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        got = list(ex.map(lambda f: up.enhance(f, outscale=4)[0], list(frames) * 2))
+    for k, g in enumerate(got):
+        assert np.array_equal(g, serial[k % len(frames)])
+
+    # (2) enhance_frame_pytorch from a pool, one frame failing with OOM in the middle
+    real_enhance = R.HipRealESRGANer.enhance
+    hit = {"n": 0}
+
+    def flaky(self, img, outscale=None, alpha_upsampler="realesrgan"):
+        hit["n"] += 1
+        if hit["n"] == 5:
+            raise _lib.FramewrightOutOfMemory(_lib.FW_ERR_OOM, "GPU out of memory: injected")
+        return real_enhance(self, img, outscale, alpha_upsampler)
+
+    monkeypatch.setattr(R.HipRealESRGANer, "enhance", flaky)
+
+    def job(i):
+        return i, R.enhance_frame_pytorch(tmp_path / f"in_{i:02d}.png", tmp_path / f"out_{i:02d}.png", cfg)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        results = dict(ex.map(job, range(len(frames))))
+    failed = [i for i, (ok, _) in results.items() if not ok]
+    assert len(failed) >= 1
+    msgs = [results[i][1] for i in failed]
+    assert any("memory" in m.lower() for m in msgs)            # restorer.py:1746's tile downshift keys on this word
+    for i, (ok, err) in results.items():
+        if ok:
+            out = np.asarray(Image.open(tmp_path / f"out_{i:02d}.png"))[:, :, ::-1]
+            assert np.array_equal(out, serial[i]), i
+        else:
+            assert isinstance(err, str) and err                   # reported, never raised
+    # the cache was cleared by the OOM handler; the next call builds a fresh upsampler and works
+    monkeypatch.setattr(R.HipRealESRGANer, "enhance", real_enhance)
+    ok, err = R.enhance_frame_pytorch(tmp_path / "in_00.png", tmp_path / "again.png", cfg)
+    assert ok and err is None
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "again.png"))[:, :, ::-1], serial[0])
+    # a closed engine refuses calls instead of touching freed memory
+    eng = R.get_upsampler(cfg).engine
+    R.clear_upsampler_cache()
+    with pytest.raises(_lib.FramewrightHipError, match="closed"):
+        eng.upscale(frames[0])

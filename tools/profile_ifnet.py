@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""IFNet v4.6 on one 1080p pair (5 iterations) for rocprofv3 --kernel-trace --stats."""
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+from framewright_amd import rife as RF
+from framewright_amd.synth import synthetic_frames, synthetic_ifnet_state
+fr = synthetic_frames(2, 1080, 1920, seed=3)
+a, b = torch.from_numpy(fr[0]).cuda(), torch.from_numpy(fr[1]).cuda()
+eng = RF.IFNetEngine("f16"); eng.load_state_dict(synthetic_ifnet_state())
+out = torch.empty_like(a)
+for _ in range(5):
+    eng.interpolate_device(a, b, out=out)
+torch.cuda.synchronize()

@@ -194,9 +194,13 @@ def sharded_tap_denoise_device(tap, frames: Sequence, halo_device=None) -> Dict[
     return {lo + j: o for j, o in enumerate(out)}
 
 
-def sharded_interpolate_device(engine, frames: Sequence) -> Dict[int, object]:
-    """BASELINE configs[2] sharded: mid-frames of this rank's pairs on an IFNetEngine, frames and halo as uint8 CUDA tensors."""
+def sharded_interpolate_device(engine, frames: Sequence, halo_device=None) -> Dict[int, object]:
+    """BASELINE configs[2] sharded: mid-frames of this rank's pairs on an IFNetEngine, frames and halo as uint8 CUDA tensors
+    (``halo_device="cpu"``: the halo crosses a gloo process group as a CPU tensor)."""
     import torch
     dev = torch.device("cuda", engine.device_id)
-    fr = [None if f is None else _as_tensor(f, dev) for f in frames]
-    return sharded_pairs(fr, lambda a, b: engine.interpolate_device(a, b, 0.5), device=dev)
+    rank, world = _dist_info()
+    lo, hi = block_partition(len(frames), world)[rank]
+    fr = [_as_tensor(f, dev) if (lo <= i < hi or (world == 1 and f is not None)) and f is not None else None for i, f in enumerate(frames)]
+    hd = dev if halo_device is None else torch.device(halo_device)
+    return sharded_pairs(fr, lambda a, b: engine.interpolate_device(a.to(dev), b.to(dev), 0.5), device=hd)
