@@ -417,6 +417,15 @@ int fw_restormer_denoise_u8(fw_restormer* net, const uint8_t* in_bgr, int in_loc
 size_t fw_restormer_workspace_bytes(fw_restormer* net, int height, int width);   /* 0 before finalize */
 int fw_restormer_destroy(fw_restormer* net);
 
+/* `TemporalDenoiser._preserve_edges` (reference src/framewright/processors/temporal_denoise.py:1636-1667): the Canny edges of
+ * `original` (cv2.Canny(gray, t, 3t) on cv2.cvtColor(BGR2GRAY)), dilated 3x3 and blurred (GaussianBlur((5, 5), 0) of edges / 255)
+ * into a float mask, blend `original` over `denoised`: out = (original * mask + denoised * (1 - mask)).astype(uint8).  uint8 BGR
+ * H x W x 3 device buffers; `scratch`: fw_preserve_edges_scratch_bytes(height, width) bytes of device memory.  OpenCV's 8-bit
+ * algorithms, restated (oracle/temporal_ref.py).  The hysteresis iterates to its fixed point: the call synchronises `stream`. */
+size_t fw_preserve_edges_scratch_bytes(int height, int width);
+int fw_preserve_edges_u8(const uint8_t* original, const uint8_t* denoised, int height, int width, double low_threshold,
+                         double high_threshold, void* scratch, uint8_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

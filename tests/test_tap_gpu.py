@@ -257,3 +257,35 @@ def test_clip_driver_with_preserve_grain(hip_lib, tmp_path, monkeypatch):
     np.testing.assert_array_equal(outs[0], tap_ref.grain_addback(frames[0], full[0], 0.3 * 1.0))
     np.testing.assert_array_equal(outs[1], tap_ref.grain_addback(frames[1], tap_ref.strength_blend(frames[1], full[1], 0.4), 0.3 * 0.4))
     m.clear_cache()
+
+
+@pytest.mark.parametrize("H,W", [(272, 400), (1080, 1920)])
+def test_deep_level_gemm_kernel_equals_the_staged_kernel(hip_lib, monkeypatch, H, W):
+    """The pipelined GEMM kernel of the >= 256-channel levels (pointwise_gemm.hip: 256 x 256 tiles, LDS-DMA, SimpleGate / residual
+    epilogues, SCA folded into scaled weights) against the register-staged pointwise kernel it replaces there (FW_NAF_GEMM=0):
+    the same fp32 accumulation of the same rounded operands up to summation order, except for conv3, whose SCA factor multiplies
+    the weights instead of the activations (one more rounding of an operand).  At 272 x 400 the deep levels have 425 / 119 / 34
+    pixels (ragged pixel tiles, rows clamped); 1080p is the BASELINE size (several tiles per workgroup)."""
+    sd = synthetic_nafnet_state(seed=11, **FULL)
+    frame = synthetic_frames(1, H, W, seed=3)[0]
+    t = torch.from_numpy(frame).cuda()
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FW_NAF_GEMM", mode)
+        eng = T.NAFNetEngine(dtype="f16", **FULL)
+        eng.load_state_dict(sd)
+        rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        u8 = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+        eng.denoise_device(t, out=u8, out_rgb_f32=rgb)
+        eng.denoise_device(t, out=u8, out_rgb_f32=rgb)            # twice: deterministic, no state left behind
+        torch.cuda.synchronize()
+        outs.append((rgb.cpu().numpy(), u8.cpu().numpy()))
+        eng.close()
+    (ra, ua), (rb, ub) = outs
+    assert np.isfinite(ra).all()
+    assert np.abs(ra - rb).max() < 1e-3 and np.abs(ra - rb).mean() < 5e-5
+    assert np.abs(ua.astype(int) - ub.astype(int)).max() <= 1
+    if H <= 300:
+        with torch.no_grad():
+            want = _oracle_model(sd, FULL)(tap_ref.preprocess(frame)).squeeze(0).permute(1, 2, 0).numpy()
+        assert np.abs(ra - want).max() < 2e-3

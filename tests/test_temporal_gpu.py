@@ -82,3 +82,34 @@ def test_flow_accumulate_matches_reference_run(hip_lib):
         acc = TD.DeviceTemporalAccumulator(temporal_weight_decay=c["decay"], flow_fn=flow_fn)
         np.testing.assert_array_equal(acc.denoise_with_flow(c["center"], window), arrs[k + "_out"])
         np.testing.assert_array_equal(acc.denoise_simple(frames), arrs[k + "_simple"])
+
+
+@pytest.mark.parametrize("h,w,thr", [(40, 56, 30), (33, 70, 30), (64, 64, 10), (7, 9, 30), (1, 12, 30), (130, 97, 60)])
+def test_preserve_edges_bit_exact(hip_lib, h, w, thr):
+    """fw_preserve_edges_u8 (gray, Sobel, non-maximum suppression, hysteresis across 32x32 tiles, dilate, 5x5 Gaussian, blend)
+    against oracle/temporal_ref.preserve_edges; shapes include several hysteresis tiles, ragged edges and a one-row image."""
+    rng = np.random.default_rng(h * 1000 + w)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = 128 + 70 * np.sin(xx / 5.0) * np.cos(yy / 7.0) + 60 * ((xx // 9 + yy // 11) % 2)
+    orig = np.clip(np.stack([base + 10 * c for c in range(3)], 2) + rng.normal(0, 6, (h, w, 3)), 0, 255).astype(np.uint8)
+    den = np.clip(orig.astype(int) + rng.integers(-25, 25, orig.shape), 0, 255).astype(np.uint8)
+    acc = TD.DeviceTemporalAccumulator()
+    got = acc.preserve_edges(orig, den, thr)
+    want = ref.preserve_edges(orig, den, thr)
+    np.testing.assert_array_equal(got, want)
+    edges = ref.canny_u8(ref.bgr2gray_u8(orig), thr, 3 * thr)
+    if h > 4:
+        assert 0 < edges.mean() < 255                      # there are edges and non-edges: both blend branches ran
+
+
+def test_preserve_edges_long_weak_chain_crosses_tiles(hip_lib):
+    """One strong pixel at the left end of a long weak ridge: the hysteresis has to carry the edge through every 32-pixel tile."""
+    h, w = 20, 200
+    orig = np.full((h, w, 3), 100, np.uint8)
+    orig[10:, :, :] = 112                                   # a weak horizontal step (L1 magnitude 4 * 12 = 48: above 30, below 90)
+    orig[10:, :3, :] = 160                                  # ... that is strong at its left end (4 * 60 > 90)
+    den = np.full_like(orig, 50)
+    gray = ref.bgr2gray_u8(orig)
+    e = ref.canny_u8(gray, 30, 90)
+    assert e[:, 150:].max() == 255 and ref.canny_u8(gray[:, 8:], 30, 90).max() == 0     # the chain only exists through its strong end
+    np.testing.assert_array_equal(TD.DeviceTemporalAccumulator().preserve_edges(orig, den, 30), ref.preserve_edges(orig, den, 30))

@@ -1,11 +1,22 @@
-import sys, time; sys.path.insert(0, ".")
+#!/usr/bin/env python3
+"""NAFNet-width64 1080p forward (ms): the deep levels on the pipelined GEMM kernel (default) and on the staged kernel (FW_NAF_GEMM=0)."""
+import json, os, subprocess, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+CHILD = r"""
+import json, sys, time
+sys.path.insert(0, %r)
 import torch
 from framewright_amd import tap_denoise as T
 from framewright_amd.synth import synthetic_frames, synthetic_nafnet_state
-f = torch.from_numpy(synthetic_frames(1, 1080, 1920, seed=4)[0]).cuda()
+f = torch.from_numpy(synthetic_frames(1, 1080, 1920, seed=4)[0]).cuda(); out = torch.empty_like(f)
 eng = T.NAFNetEngine(dtype="f16", **T.NAFNET_ARGS); eng.load_state_dict(synthetic_nafnet_state(**T.NAFNET_ARGS))
-out = torch.empty_like(f)
-for _ in range(2): eng.denoise_device(f, out=out)
+for _ in range(3): eng.denoise_device(f, out=out)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(5): eng.denoise_device(f, out=out)
-torch.cuda.synchronize(); print("nafnet 1080p ms", (time.perf_counter() - t0) / 5 * 1e3)
+N = 20
+for _ in range(N): eng.denoise_device(f, out=out)
+torch.cuda.synchronize(); print(json.dumps({"ms": (time.perf_counter() - t0) / N * 1e3, "checksum": int(out[::7, ::5].to(torch.int64).sum())}))
+"""
+for name, env in (("gemm", {}), ("staged", {"FW_NAF_GEMM": "0"}), ("gemm_again", {})):
+    r = subprocess.run([sys.executable, "-c", CHILD % str(ROOT)], capture_output=True, text=True, env=dict(os.environ, **env))
+    print(name, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-500:], flush=True)

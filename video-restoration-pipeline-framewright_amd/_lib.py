@@ -33,7 +33,7 @@ EXPORTS = [
     "fw_ifnet_create", "fw_ifnet_set_tensor", "fw_ifnet_finalize", "fw_ifnet_interp_u8", "fw_ifnet_workspace_bytes", "fw_ifnet_flops",
     "fw_ifnet_destroy",
     "fw_restormer_create", "fw_restormer_set_tensor", "fw_restormer_finalize", "fw_restormer_denoise_u8",
-    "fw_restormer_workspace_bytes", "fw_restormer_destroy",
+    "fw_restormer_workspace_bytes", "fw_restormer_destroy", "fw_preserve_edges_scratch_bytes", "fw_preserve_edges_u8",
     "fw_u8_to_nhwc", "fw_pixel_shuffle_add_u8",
     "fw_layernorm_nhwc", "fw_pack_pointwise", "fw_pointwise_nhwc", "fw_dwconv3x3_nhwc", "fw_attn_workspace_floats",
     "fw_attn_matrix", "fw_attn_apply", "fw_attn_pack", "fw_pixel_shuffle2_f32", "fw_copy_channels_f32", "fw_f32_to_planar", "fw_tap_post_u8",
@@ -169,6 +169,10 @@ def _declare_ifnet(lib: C.CDLL) -> None:
     lib.fw_restormer_workspace_bytes.argtypes = [vp, i32, i32]
     lib.fw_restormer_destroy.restype = i32
     lib.fw_restormer_destroy.argtypes = [vp]
+    lib.fw_preserve_edges_scratch_bytes.restype = sz
+    lib.fw_preserve_edges_scratch_bytes.argtypes = [i32, i32]
+    lib.fw_preserve_edges_u8.restype = i32
+    lib.fw_preserve_edges_u8.argtypes = [vp, vp, i32, i32, C.c_double, C.c_double, vp, vp, vp]
     lib.fw_unsharp_mask_u8.restype = i32
     lib.fw_unsharp_mask_u8.argtypes = [vp, i32, i32, i32, i32, C.c_uint, C.c_uint, i32, i32, i32, vp, vp, vp, vp]
     lib.fw_u8_to_nhwc.restype = i32

@@ -224,6 +224,26 @@ __device__ __forceinline__ void glds16_batch_a(const void* sbase, const unsigned
         : "memory");
 }
 
+// Four pieces with their own per-lane offsets (the GEMM kernel's activation rows); voff[i] already contains -(i - 3) KiB and
+// lds_piece3 is the LDS address of the FOURTH piece.
+__device__ __forceinline__ void glds16_batch_a4(const void* sbase, const unsigned* voff, unsigned lds_piece3) {
+    const unsigned long long b = (unsigned long long)sbase;
+    const unsigned long long sb = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) << 32) |
+                                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)b);
+    lds_piece3 = __builtin_amdgcn_readfirstlane(lds_piece3);
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 m0, %5\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %4 offset:-3072\n\t"
+        "global_load_lds_dwordx4 %1, %4 offset:-2048\n\t"
+        "global_load_lds_dwordx4 %2, %4 offset:-1024\n\t"
+        "global_load_lds_dwordx4 %3, %4"
+        :
+        : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(sb), "s"(lds_piece3)
+        : "memory");
+}
+
 // The same transfer with a per-lane 64-bit source address (border tiles: pieces outside the image read the zero page, so
 // every wave still issues exactly one DMA per piece - the counted vmcnt waits rely on that).
 __device__ __forceinline__ void glds16_v(const void* gsrc, unsigned lds_dst) {

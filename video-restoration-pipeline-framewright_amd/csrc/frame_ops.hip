@@ -598,4 +598,179 @@ void launch_grain_addback(const uint8_t* orig, const uint8_t* den, int H, int W,
     FW_HIP_CHECK(hipGetLastError());
 }
 
+// ---- `_preserve_edges` of the classical temporal denoiser (temporal_denoise.py:1636-1667) ----------------------------------------
+//   gray = BGR2GRAY(original); edges = Canny(gray, t, 3t); edges = dilate(edges, 3x3); mask = GaussianBlur(edges / 255, (5, 5), 0)
+//   out  = (original * mask + denoised * (1 - mask)).astype(uint8)
+// OpenCV's 8-bit algorithms restated (oracle/temporal_ref.py has the same statement in numpy and the citations): 14-bit gray
+// weights, Sobel 3x3 with replicated borders, L1 magnitude, the fixed-point tangent test of the non-maximum suppression,
+// hysteresis, 3x3 maximum, the fixed [1 4 6 4 1] / 16 float32 kernel with BORDER_REFLECT_101.  This file is compiled without FMA
+// contraction, so the float32 passes round exactly like numpy's.
+__device__ __forceinline__ int pe_gray(const uint8_t* __restrict__ bgr, int H, int W, int y, int x) {
+    y = min(max(y, 0), H - 1);   // BORDER_REPLICATE of the Sobel
+    x = min(max(x, 0), W - 1);
+    const uint8_t* p = bgr + ((long)y * W + x) * 3;
+    return (p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + (1 << 13)) >> 14;
+}
+
+// dx, dy (int16) and the L1 magnitude of every pixel
+__global__ __launch_bounds__(256) void pe_sobel_kernel(const uint8_t* __restrict__ bgr, int H, int W, short* __restrict__ dxy,
+                                                       short* __restrict__ mag) {
+    const long n = (long)H * W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W), x = (int)(i - (long)y * W);
+        int g[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = pe_gray(bgr, H, W, y + a - 1, x + b - 1);
+        const int dx = (g[0][2] + 2 * g[1][2] + g[2][2]) - (g[0][0] + 2 * g[1][0] + g[2][0]);
+        const int dy = (g[2][0] + 2 * g[2][1] + g[2][2]) - (g[0][0] + 2 * g[0][1] + g[0][2]);
+        dxy[2 * i] = (short)dx;
+        dxy[2 * i + 1] = (short)dy;
+        mag[i] = (short)(abs(dx) + abs(dy));
+    }
+}
+
+// non-maximum suppression: map = 2 (above `high`: an edge), 0 (above `low`: an edge if connected to one), 1 (no edge)
+__global__ __launch_bounds__(256) void pe_nms_kernel(const short* __restrict__ dxy, const short* __restrict__ mag, int H, int W, int lo,
+                                                     int hi, uint8_t* __restrict__ map) {
+    const long n = (long)H * W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W), x = (int)(i - (long)y * W);
+        auto M = [&](int yy, int xx) { return (yy < 0 || yy >= H || xx < 0 || xx >= W) ? 0 : (int)mag[(long)yy * W + xx]; };
+        const int m = mag[i], xs = dxy[2 * i], ys = dxy[2 * i + 1];
+        uint8_t v = 1;
+        if (m > lo) {
+            const long ax = abs(xs), ay = (long)abs(ys) << 15;
+            const long tg22 = ax * 13573;
+            bool keep;
+            if (ay < tg22) {
+                keep = m > M(y, x - 1) && m >= M(y, x + 1);
+            } else if (ay > tg22 + (ax << 16)) {
+                keep = m > M(y - 1, x) && m >= M(y + 1, x);
+            } else {
+                const int s = (xs ^ ys) < 0 ? -1 : 1;
+                keep = m > M(y - 1, x - s) && m > M(y + 1, x + s);
+            }
+            if (keep) v = m > hi ? 2 : 0;
+        }
+        map[i] = v;
+    }
+}
+
+// hysteresis: one 32 x 32 tile (with a one-pixel ring) per workgroup is grown to its fixed point in LDS; the host repeats the
+// launch until no tile changed.  Only 0 -> 2 transitions exist, so the fixed point does not depend on the order of the sweeps.
+__global__ __launch_bounds__(256) void pe_hysteresis_kernel(uint8_t* __restrict__ map, int H, int W, int* __restrict__ changed) {
+    __shared__ uint8_t t[34][36];
+    const int tiles_x = (W + 31) / 32;
+    const int ty0 = (blockIdx.x / tiles_x) * 32, tx0 = (blockIdx.x % tiles_x) * 32;
+    for (int k = threadIdx.x; k < 34 * 34; k += 256) {
+        const int yy = k / 34, xx = k - yy * 34, gy = ty0 + yy - 1, gx = tx0 + xx - 1;
+        t[yy][xx] = (gy < 0 || gy >= H || gx < 0 || gx >= W) ? 1 : map[(long)gy * W + gx];
+    }
+    __syncthreads();
+    bool any = false;
+    for (int it = 0; it < 1024; ++it) {
+        bool ch = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = threadIdx.x + 256 * q, yy = 1 + k / 32, xx = 1 + (k & 31);
+            if (t[yy][xx] == 0) {
+                bool nb = false;
+#pragma unroll
+                for (int a = -1; a <= 1; ++a)
+#pragma unroll
+                    for (int b = -1; b <= 1; ++b) nb |= t[yy + a][xx + b] == 2;
+                if (nb) {
+                    t[yy][xx] = 2;
+                    ch = true;
+                }
+            }
+        }
+        if (!__syncthreads_or(ch)) break;
+        any = true;
+    }
+    if (any) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = threadIdx.x + 256 * q, yy = 1 + k / 32, xx = 1 + (k & 31), gy = ty0 + yy - 1, gx = tx0 + xx - 1;
+            if (gy < H && gx < W) map[(long)gy * W + gx] = t[yy][xx];
+        }
+        if (threadIdx.x == 0) atomicOr(changed, 1);
+    }
+}
+
+// 3x3 maximum of the edge image (map == 2), then the horizontal pass of the 5-tap Gaussian on edges / 255 (0.0f or 1.0f)
+__global__ __launch_bounds__(256) void pe_mask_rows_kernel(const uint8_t* __restrict__ map, int H, int W, float* __restrict__ rows) {
+    const long n = (long)H * W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W), x = (int)(i - (long)y * W);
+        auto refl = [](int v, int len) { return len == 1 ? 0 : (v < 0 ? -v : (v >= len ? 2 * len - 2 - v : v)); };
+        auto dil = [&](int xx) {   // dilated edge value at (y, xx), xx inside the image
+            for (int a = -1; a <= 1; ++a)
+                for (int b = -1; b <= 1; ++b) {
+                    const int yy = y + a, x2 = xx + b;
+                    if (yy >= 0 && yy < H && x2 >= 0 && x2 < W && map[(long)yy * W + x2] == 2) return 1.0f;
+                }
+            return 0.0f;
+        };
+        float c = dil(x);
+        float l1 = dil(min(max(refl(x - 1, W), 0), W - 1)), r1 = dil(min(max(refl(x + 1, W), 0), W - 1));
+        float l2 = dil(min(max(refl(x - 2, W), 0), W - 1)), r2 = dil(min(max(refl(x + 2, W), 0), W - 1));
+        rows[i] = (c * 0.375f + (l1 + r1) * 0.25f) + ((l2 + r2) * 0.0625f);
+    }
+}
+
+// vertical pass + blend
+__global__ __launch_bounds__(256) void pe_blend_kernel(const uint8_t* __restrict__ orig, const uint8_t* __restrict__ den,
+                                                       const float* __restrict__ rows, int H, int W, uint8_t* __restrict__ out) {
+    const long n = (long)H * W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W), x = (int)(i - (long)y * W);
+        auto R = [&](int yy) {
+            yy = H == 1 ? 0 : (yy < 0 ? -yy : (yy >= H ? 2 * H - 2 - yy : yy));
+            yy = min(max(yy, 0), H - 1);
+            return rows[(long)yy * W + x];
+        };
+        const float mask = (R(y) * 0.375f + (R(y - 1) + R(y + 1)) * 0.25f) + ((R(y - 2) + R(y + 2)) * 0.0625f);
+        const float inv = 1.0f - mask;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = (float)orig[i * 3 + c] * mask + (float)den[i * 3 + c] * inv;
+            out[i * 3 + c] = (uint8_t)v;
+        }
+    }
+}
+
+size_t preserve_edges_scratch_bytes(int H, int W) {
+    const size_t n = (size_t)H * W;
+    return n * (4 + 2 + 1 + 4) + 256 + 64;
+}
+
+void launch_preserve_edges(const uint8_t* orig, const uint8_t* den, int H, int W, int lo, int hi, void* scratch, uint8_t* out,
+                           hipStream_t st) {
+    const size_t n = (size_t)H * W;
+    char* s = (char*)scratch;
+    short* dxy = (short*)s;
+    short* mag = (short*)(s + n * 4);
+    float* rows = (float*)(s + ((n * 6 + 255) / 256) * 256);
+    uint8_t* map = (uint8_t*)(rows + n);
+    int* changed = (int*)(((size_t)(map + n) + 63) / 64 * 64);
+    const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(pe_sobel_kernel, dim3(blocks), dim3(256), 0, st, orig, H, W, dxy, mag);
+    hipLaunchKernelGGL(pe_nms_kernel, dim3(blocks), dim3(256), 0, st, dxy, mag, H, W, lo, hi, map);
+    const int tiles = ((W + 31) / 32) * ((H + 31) / 32);
+    for (int round = 0; round < 4096; ++round) {   // a chain of weak pixels crosses at most this many tiles
+        FW_HIP_CHECK(hipMemsetAsync(changed, 0, 4, st));
+        hipLaunchKernelGGL(pe_hysteresis_kernel, dim3(tiles), dim3(256), 0, st, map, H, W, changed);
+        int flag = 0;
+        FW_HIP_CHECK(hipMemcpyAsync(&flag, changed, 4, hipMemcpyDeviceToHost, st));
+        FW_HIP_CHECK(hipStreamSynchronize(st));
+        if (!flag) break;
+    }
+    hipLaunchKernelGGL(pe_mask_rows_kernel, dim3(blocks), dim3(256), 0, st, map, H, W, rows);
+    hipLaunchKernelGGL(pe_blend_kernel, dim3(blocks), dim3(256), 0, st, orig, den, rows, H, W, out);
+    FW_HIP_CHECK(hipGetLastError());
+}
+
 }  // namespace fw

@@ -137,6 +137,8 @@ struct PointwiseParams {
     const float* ln_b;     //   over the 64 channels of each pixel, eps = ln_eps; null = off
     float ln_eps;
     const void* wpk;       // pack_pointwise_weights
+    const void* wpk16;     // optional: the same weights in pack_pointwise_weights16's layout - with it, typed inputs and
+                           // K >= 256, cout % 256 == 0, the pipelined GEMM kernel (pointwise_gemm.hip) runs instead
     const float* bias;     // [32*N_tiles] or null
     int N_tiles;           // cout / 32
     int mode;
@@ -150,6 +152,12 @@ struct PointwiseParams {
 
 void launch_pointwise(DType dt, const PointwiseParams& p, hipStream_t st);
 size_t pack_pointwise_weights(DType dt, const float* w, int cout, int K, uint16_t* dst);
+// pointwise_gemm.hip: the many-channel form (256 x 256 tiles, LDS-DMA pipeline)
+bool pointwise_gemm_eligible(const PointwiseParams& p);
+void launch_pointwise_gemm(DType dt, const PointwiseParams& p, hipStream_t st);
+size_t pack_pointwise_weights16(DType dt, const float* w, int cout, int K, int gate, uint16_t* dst);
+// dst = src (pack_pointwise_weights16 layout, cout N x K) with input channel k scaled by scale[k] (NAFNet's SCA in front of conv3)
+void launch_pw16_scale_weights(DType dt, const void* src, const float* scale, int N, int K, void* dst, hipStream_t st);
 void launch_layernorm2d(DType dt, const float* x, long M, int C, const float* w, const float* b, void* out,
                         hipStream_t st);
 int dwconv_blocks(int H, int W, int C);  // grid of the dwconv kernel = rows of its `partial` output
@@ -180,6 +188,10 @@ void launch_grain_addback(const uint8_t* orig, const uint8_t* den, int H, int W,
 // cv2.resize(INTER_LANCZOS4) on 8-bit H x W x C images (device pointers); synchronises the stream
 void launch_resize_lanczos4_u8(const uint8_t* src, int Hs, int Ws, int C, uint8_t* dst, int Hd, int Wd, hipStream_t st);
 void launch_flow_accumulate_finish(const double* acc, const double* wsum, long n, uint8_t* out, hipStream_t st);
+// `_preserve_edges` (temporal_denoise.py:1636-1667): Canny edge mask of `orig` blends it over `den`; synchronises the stream
+size_t preserve_edges_scratch_bytes(int H, int W);
+void launch_preserve_edges(const uint8_t* orig, const uint8_t* den, int H, int W, int lo, int hi, void* scratch, uint8_t* out,
+                           hipStream_t st);
 
 // ---- IFNet building blocks (ifnet_ops.hip), used by the whole-model engine in ifnet.hip -------------------------------------
 void launch_ifnet_u8_to_rgb(const uint8_t* in_bgr, int H, int W, int Hp, int Wp, float* out, hipStream_t st);

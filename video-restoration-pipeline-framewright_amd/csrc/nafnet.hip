@@ -5,6 +5,7 @@
 // :373-415 (pre/post-processing: BGR->RGB, /255, ... np.clip(x*255, 0, 255).astype(uint8) — truncation), :458 (the
 // forward).  The network itself lives in a third-party package that is absent here; the architecture follows
 // SURVEY.md §A.3 and the oracle is oracle/nafnet_ref.py ("parity vs upstream unpinned").
+#include <cmath>
 #include <map>
 #include <mutex>
 #include <memory>
@@ -34,6 +35,7 @@ struct Block {
     // device weights
     DevBuf n1w, n1b, n2w, n2b, beta, gamma;            // fp32 [c]
     DevBuf w1, b1, w3, b3, w4, b4, w5, b5;             // packed pointwise weights + fp32 biases
+    DevBuf w1g, w3g, w4g, w5g;                         // the same in pack_pointwise_weights16's layout (c >= 256: the GEMM kernel)
     DevBuf wdw, bdw;                                   // depthwise fp32 [2c][9], [2c]
     DevBuf wsca, bsca;                                 // fp32 [c][c], [c]
     unsigned have = 0;                                 // bit per tensor
@@ -61,6 +63,7 @@ struct fw_nafnet {
     bool have_intro_w = false, have_intro_b = false, have_end_w = false, have_end_b = false;
     DevBuf ws;
     bool fuse_ln = true;   // LayerNorm2d inside the staging pass of the GEMM that follows it at width 64 (FW_NAF_FUSE_LN=0: A/B)
+    bool gemm = true;      // 1x1 convs of the levels with >= 256 channels on pointwise_gemm.hip (FW_NAF_GEMM=0: A/B)
 };
 
 namespace {
@@ -102,6 +105,13 @@ void upload(DevBuf& b, const void* src, size_t bytes) {
 void upload_pointwise(DType dt, DevBuf& b, const float* w, int cout, int K) {
     std::vector<uint16_t> pk(pack_pointwise_weights(dt, nullptr, cout, K, nullptr));
     pack_pointwise_weights(dt, w, cout, K, pk.data());
+    upload(b, pk.data(), pk.size() * 2);
+}
+
+// the deep levels run their 1x1 convs on the pipelined GEMM kernel (pointwise_gemm.hip): a second packing of the same weights
+void upload_pointwise16(DType dt, DevBuf& b, const float* w, int cout, int K, int gate) {
+    std::vector<uint16_t> pk(pack_pointwise_weights16(dt, nullptr, cout, K, gate, nullptr));
+    pack_pointwise_weights16(dt, w, cout, K, gate, pk.data());
     upload(b, pk.data(), pk.size() * 2);
 }
 
@@ -155,15 +165,15 @@ void set_block_tensor(fw_nafnet* n, Block& bl, const std::string& name, const st
     else if (name == "norm2.bias") { need(numel, c, key); upload(bl.n2b, d, c * 4); mark(3); }
     else if (name == "beta") { need(numel, c, key); upload(bl.beta, d, c * 4); mark(4); }
     else if (name == "gamma") { need(numel, c, key); upload(bl.gamma, d, c * 4); mark(5); }
-    else if (name == "conv1.weight") { need(numel, (size_t)2 * c * c, key); upload_pointwise(n->dt, bl.w1, d, 2 * c, c); mark(6); }
+    else if (name == "conv1.weight") { need(numel, (size_t)2 * c * c, key); upload_pointwise(n->dt, bl.w1, d, 2 * c, c); if (n->gemm && c >= 256) upload_pointwise16(n->dt, bl.w1g, d, 2 * c, c, 0); mark(6); }
     else if (name == "conv1.bias") { need(numel, 2 * c, key); upload(bl.b1, d, 2 * c * 4); mark(7); }
     else if (name == "conv2.weight") { need(numel, (size_t)2 * c * 9, key); upload(bl.wdw, d, (size_t)2 * c * 9 * 4); mark(8); }
     else if (name == "conv2.bias") { need(numel, 2 * c, key); upload(bl.bdw, d, 2 * c * 4); mark(9); }
-    else if (name == "conv3.weight") { need(numel, (size_t)c * c, key); upload_pointwise(n->dt, bl.w3, d, c, c); mark(10); }
+    else if (name == "conv3.weight") { need(numel, (size_t)c * c, key); upload_pointwise(n->dt, bl.w3, d, c, c); if (n->gemm && c >= 256) upload_pointwise16(n->dt, bl.w3g, d, c, c, 0); mark(10); }
     else if (name == "conv3.bias") { need(numel, c, key); upload(bl.b3, d, c * 4); mark(11); }
-    else if (name == "conv4.weight") { need(numel, (size_t)2 * c * c, key); upload_pointwise(n->dt, bl.w4, d, 2 * c, c); mark(12); }
+    else if (name == "conv4.weight") { need(numel, (size_t)2 * c * c, key); upload_pointwise(n->dt, bl.w4, d, 2 * c, c); if (n->gemm && c >= 256) upload_pointwise16(n->dt, bl.w4g, d, 2 * c, c, 1); mark(12); }
     else if (name == "conv4.bias") { need(numel, 2 * c, key); upload(bl.b4, d, 2 * c * 4); mark(13); }
-    else if (name == "conv5.weight") { need(numel, (size_t)c * c, key); upload_pointwise(n->dt, bl.w5, d, c, c); mark(14); }
+    else if (name == "conv5.weight") { need(numel, (size_t)c * c, key); upload_pointwise(n->dt, bl.w5, d, c, c); if (n->gemm && c >= 256) upload_pointwise16(n->dt, bl.w5g, d, c, c, 0); mark(14); }
     else if (name == "conv5.bias") { need(numel, c, key); upload(bl.b5, d, c * 4); mark(15); }
     else if (name == "sca.1.weight") { need(numel, (size_t)c * c, key); upload(bl.wsca, d, (size_t)c * c * 4); mark(16); }
     else if (name == "sca.1.bias") { need(numel, c, key); upload(bl.bsca, d, c * 4); mark(17); }
@@ -172,7 +182,7 @@ void set_block_tensor(fw_nafnet* n, Block& bl, const std::string& name, const st
 
 struct Plan {
     int Hp, Wp;
-    size_t in_u8, out_u8, img32, S[8], T1, T2, T3, csum, sca, cat64, rgb, total;
+    size_t in_u8, out_u8, img32, S[8], T1, T2, T3, csum, sca, w3s, cat64, rgb, total;
 };
 
 size_t up256(size_t v) { return (v + 255) / 256 * 256; }
@@ -194,6 +204,7 @@ Plan make_plan(const fw_nafnet* n, int H, int W) {
     p.T3 = take(M0 * n->width * 2);
     p.csum = take((size_t)1024 * 1024 * 4);  // dwconv partial sums [<=1024 blocks][<=1024 channels]
     p.sca = take(2 * 1024 * 4);  // SCA scale [C] + pooled mean [C]
+    p.w3s = take((size_t)1024 * 1024 * 2);  // conv3's packed weights scaled by the SCA factors (<= 1024 x 1024)
     p.cat64 = take(M0 * n->width * 2);
     p.rgb = take(M0 * 3 * 4);
     p.total = o;
@@ -218,7 +229,7 @@ void run_block(fw_nafnet* n, const Block& b, float* S, int H, int W, char* ws, c
         launch_layernorm2d(n->dt, S, M, c, (const float*)b.n1w.p, (const float*)b.n1b.p, T1, st);
         p.a = T1;
     }
-    p.lda = c; p.M = M; p.K = c; p.wpk = b.w1.p; p.bias = (const float*)b.b1.p; p.N_tiles = 2 * c / 32;
+    p.lda = c; p.M = M; p.K = c; p.wpk = b.w1.p; p.wpk16 = b.w1g.p; p.bias = (const float*)b.b1.p; p.N_tiles = 2 * c / 32;
     p.mode = PW_STORE; p.out_typed = T2; p.ldo = 2 * c;
     launch_pointwise(n->dt, p, st);
     // x = SimpleGate(conv2(x)); pooled sums for SCA
@@ -228,6 +239,11 @@ void run_block(fw_nafnet* n, const Block& b, float* S, int H, int W, char* ws, c
     p = PointwiseParams{};
     p.a = T3; p.lda = c; p.M = M; p.K = c; p.a_scale = sca; p.wpk = b.w3.p; p.bias = (const float*)b.b3.p; p.N_tiles = c / 32;
     p.mode = PW_RESIDUAL; p.out_f32 = S; p.res_f32 = S; p.ldf = c; p.chan_scale = (const float*)b.beta.p;
+    if (b.w3g.p) {   // the GEMM kernel does not touch its activations: the SCA factors go into a scaled copy of the weights
+        launch_pw16_scale_weights(n->dt, b.w3g.p, sca, c, c, ws + pl.w3s, st);
+        p.wpk16 = ws + pl.w3s;
+        p.a_scale = nullptr;
+    }
     launch_pointwise(n->dt, p, st);
     // x = conv5(SimpleGate(conv4(norm2(y)))) ; out = y + x * gamma
     p = PointwiseParams{};
@@ -237,11 +253,11 @@ void run_block(fw_nafnet* n, const Block& b, float* S, int H, int W, char* ws, c
         launch_layernorm2d(n->dt, S, M, c, (const float*)b.n2w.p, (const float*)b.n2b.p, T1, st);
         p.a = T1;
     }
-    p.lda = c; p.M = M; p.K = c; p.wpk = b.w4.p; p.bias = (const float*)b.b4.p; p.N_tiles = 2 * c / 32;
+    p.lda = c; p.M = M; p.K = c; p.wpk = b.w4.p; p.wpk16 = b.w4g.p; p.bias = (const float*)b.b4.p; p.N_tiles = 2 * c / 32;
     p.mode = PW_GATE; p.out_typed = T3; p.ldo = c;
     launch_pointwise(n->dt, p, st);
     p = PointwiseParams{};
-    p.a = T3; p.lda = c; p.M = M; p.K = c; p.wpk = b.w5.p; p.bias = (const float*)b.b5.p; p.N_tiles = c / 32;
+    p.a = T3; p.lda = c; p.M = M; p.K = c; p.wpk = b.w5.p; p.wpk16 = b.w5g.p; p.bias = (const float*)b.b5.p; p.N_tiles = c / 32;
     p.mode = PW_RESIDUAL; p.out_f32 = S; p.res_f32 = S; p.ldf = c; p.chan_scale = (const float*)b.gamma.p;
     launch_pointwise(n->dt, p, st);
 }
@@ -321,6 +337,7 @@ int fw_nafnet_create(int device_id, int width, int middle_blk_num, const int* en
         if (device_id < 0 || device_id >= nd) throw Error(FW_ERR_INVALID, "fw_nafnet_create: no such device");
         auto n = std::make_unique<fw_nafnet>();
         if (const char* e = getenv("FW_NAF_FUSE_LN")) n->fuse_ln = atoi(e) != 0;
+        if (const char* e = getenv("FW_NAF_GEMM")) n->gemm = atoi(e) != 0;
         n->device = device_id;
         n->dt = (DType)dtype;
         n->width = width;
@@ -544,7 +561,7 @@ int fw_nafnet_destroy(fw_nafnet* n) {
     (void)hipSetDevice(n->device);
     (void)hipDeviceSynchronize();
     auto free_block = [](Block& b) {
-        for (DevBuf* d : {&b.n1w, &b.n1b, &b.n2w, &b.n2b, &b.beta, &b.gamma, &b.w1, &b.b1, &b.w3, &b.b3, &b.w4, &b.b4, &b.w5,
+        for (DevBuf* d : {&b.n1w, &b.n1b, &b.n2w, &b.n2b, &b.beta, &b.gamma, &b.w1, &b.b1, &b.w3, &b.b3, &b.w4, &b.b4, &b.w5, &b.w1g, &b.w3g, &b.w4g, &b.w5g,
                           &b.b5, &b.wdw, &b.bdw, &b.wsca, &b.bsca})
             d->release();
     };
@@ -558,6 +575,22 @@ int fw_nafnet_destroy(fw_nafnet* n) {
     if (prev >= 0) (void)hipSetDevice(prev);
     delete n;
     return FW_OK;
+}
+
+size_t fw_preserve_edges_scratch_bytes(int height, int width) {
+    if (height < 1 || width < 1) return 0;
+    return preserve_edges_scratch_bytes(height, width);
+}
+
+int fw_preserve_edges_u8(const uint8_t* original, const uint8_t* denoised, int height, int width, double low_threshold,
+                         double high_threshold, void* scratch, uint8_t* out, void* stream) {
+    if (!original || !denoised || !scratch || !out || height < 1 || width < 1 || !(low_threshold >= 0) || !(high_threshold >= 0))
+        return fail(FW_ERR_INVALID, "fw_preserve_edges_u8: bad argument");
+    return guarded([&] {
+        double lo = low_threshold, hi = high_threshold;
+        if (lo > hi) std::swap(lo, hi);
+        launch_preserve_edges(original, denoised, height, width, (int)floor(lo), (int)floor(hi), scratch, out, (hipStream_t)stream);
+    });
 }
 
 }  // extern "C"

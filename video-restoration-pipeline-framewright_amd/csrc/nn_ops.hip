@@ -377,6 +377,10 @@ static void launch_pw_typed(const PointwiseParams& p, hipStream_t st) {
 
 void launch_pointwise(DType dt, const PointwiseParams& p, hipStream_t st) {
     if (p.M <= 0 || p.K <= 0 || (p.K & 31) || p.N_tiles <= 0) throw Error(1, "pointwise: bad shape");
+    if (pointwise_gemm_eligible(p)) {
+        launch_pointwise_gemm(dt, p, st);
+        return;
+    }
     if (p.mode == PW_GATE && (p.N_tiles & 1)) throw Error(1, "pointwise: gate needs an even number of cout tiles");
     if (p.gather2x2 && (p.Cin & 31)) throw Error(1, "pointwise: 2x2 gather needs Cin % 32 == 0");
     if (p.ln_w && (!p.ln_b || !p.a_f32 || p.gather2x2 || p.a_scale || p.K != 64 || p.lda != 64))

@@ -117,6 +117,28 @@ class DeviceTemporalAccumulator:
                 self._accumulate(fd, None, temporal, None, None, False, acc, ws)
         return self._finish(acc, ws)
 
+    def preserve_edges(self, original: np.ndarray, denoised: np.ndarray, edge_threshold: int = 30) -> np.ndarray:
+        """`TemporalDenoiser._preserve_edges` (temporal_denoise.py:1636-1667): the original frame shows through a blurred,
+        dilated Canny edge mask (thresholds ``edge_threshold`` and three times that, config default 30, :146).  uint8 BGR frames
+        in and out; fw_preserve_edges_u8."""
+        import torch
+        if original.shape != denoised.shape or original.dtype != np.uint8 or denoised.dtype != np.uint8 or original.ndim != 3 or \
+                original.shape[2] != 3:
+            raise ValueError("preserve_edges expects two uint8 BGR frames of one size")
+        dev = self._dev()
+        h, w = original.shape[:2]
+        with torch.cuda.device(dev):
+            o = torch.from_numpy(np.ascontiguousarray(original)).to(dev)
+            d = torch.from_numpy(np.ascontiguousarray(denoised)).to(dev)
+            scratch = torch.empty(int(self._lib.fw_preserve_edges_scratch_bytes(h, w)), dtype=torch.uint8, device=dev)
+            out = torch.empty_like(o)
+            st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(self._lib.fw_preserve_edges_u8(C.c_void_p(o.data_ptr()), C.c_void_p(d.data_ptr()), h, w, float(edge_threshold),
+                                                      float(edge_threshold * 3), C.c_void_p(scratch.data_ptr()),
+                                                      C.c_void_p(out.data_ptr()), st))
+            torch.cuda.synchronize(dev)
+        return out.cpu().numpy()
+
     def denoise_simple(self, window: Sequence[np.ndarray]) -> np.ndarray:
         """`_denoise_simple` (temporal_denoise.py:1582-1605).  The reference divides by a scalar weight sum; per-pixel sums
         of the same scalars give the same float64 quotient."""
