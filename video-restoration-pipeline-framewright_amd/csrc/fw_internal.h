@@ -152,6 +152,11 @@ struct PointwiseParams {
 
 void launch_pointwise(DType dt, const PointwiseParams& p, hipStream_t st);
 size_t pack_pointwise_weights(DType dt, const float* w, int cout, int K, uint16_t* dst);
+// the second half of a width-64 NAFBlock (conv3 + beta residual + LayerNorm2d + conv4 + SimpleGate + conv5 + gamma residual) in
+// one pass over the fp32 stream; weights in pack_pointwise_weights' layout
+void launch_naf_tail64(DType dt, const void* x, const float* a_scale, float* stream, long M, const void* w3, const float* b3,
+                       const float* beta, const float* ln_w, const float* ln_b, float ln_eps, const void* w4, const float* b4,
+                       const void* w5, const float* b5, const float* gamma, hipStream_t st);
 // pointwise_gemm.hip: the many-channel form (256 x 256 tiles, LDS-DMA pipeline)
 bool pointwise_gemm_eligible(const PointwiseParams& p);
 void launch_pointwise_gemm(DType dt, const PointwiseParams& p, hipStream_t st);

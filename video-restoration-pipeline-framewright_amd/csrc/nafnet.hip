@@ -64,6 +64,7 @@ struct fw_nafnet {
     DevBuf ws;
     bool fuse_ln = true;   // LayerNorm2d inside the staging pass of the GEMM that follows it at width 64 (FW_NAF_FUSE_LN=0: A/B)
     bool gemm = true;      // 1x1 convs of the levels with >= 256 channels on pointwise_gemm.hip (FW_NAF_GEMM=0: A/B)
+    bool fuse_tail = true; // conv3 .. conv5 of a width-64 block as one kernel (FW_NAF_FUSE_TAIL=0: A/B)
 };
 
 namespace {
@@ -235,6 +236,13 @@ void run_block(fw_nafnet* n, const Block& b, float* S, int H, int W, char* ws, c
     // x = SimpleGate(conv2(x)); pooled sums for SCA
     launch_dwconv3x3_gate(n->dt, T2, H, W, c, (const float*)b.wdw.p, (const float*)b.bdw.p, T3, csum, st);
     launch_sca(csum, dwconv_blocks(H, W, c), M, c, (const float*)b.wsca.p, (const float*)b.bsca.p, sca, st);
+    if (c == 64 && n->fuse_tail) {
+        // the rest of the block in one pass over the stream (nn_ops.hip naf_tail64_kernel)
+        launch_naf_tail64(n->dt, T3, sca, S, M, b.w3.p, (const float*)b.b3.p, (const float*)b.beta.p, (const float*)b.n2w.p,
+                          (const float*)b.n2b.p, 1e-6f, b.w4.p, (const float*)b.b4.p, b.w5.p, (const float*)b.b5.p,
+                          (const float*)b.gamma.p, st);
+        return;
+    }
     // y = inp + conv3(x * sca) * beta
     p = PointwiseParams{};
     p.a = T3; p.lda = c; p.M = M; p.K = c; p.a_scale = sca; p.wpk = b.w3.p; p.bias = (const float*)b.b3.p; p.N_tiles = c / 32;
@@ -338,6 +346,7 @@ int fw_nafnet_create(int device_id, int width, int middle_blk_num, const int* en
         auto n = std::make_unique<fw_nafnet>();
         if (const char* e = getenv("FW_NAF_FUSE_LN")) n->fuse_ln = atoi(e) != 0;
         if (const char* e = getenv("FW_NAF_GEMM")) n->gemm = atoi(e) != 0;
+        if (const char* e = getenv("FW_NAF_FUSE_TAIL")) n->fuse_tail = atoi(e) != 0;
         n->device = device_id;
         n->dt = (DType)dtype;
         n->width = width;

@@ -391,6 +391,252 @@ void launch_pointwise(DType dt, const PointwiseParams& p, hipStream_t st) {
         launch_pw_typed<_Float16>(p, st);
 }
 
+// =====================================================================================================
+// The second half of a NAFBlock at width 64 as ONE kernel (the full-resolution level, where every 1x1 conv is HBM-bound):
+//   y   = inp + conv3(x * sca) * beta              x: the gated depthwise output (typed), inp: the fp32 stream
+//   out = y + conv5(SimpleGate(conv4(norm2(y)))) * gamma
+// Unfused, conv3 / conv4 (+LayerNorm, +gate) / conv5 move 640 + 384 + 640 B per pixel (the stream read three times and written
+// twice, two typed intermediates); here the stream is read once and written once and x is read once: 640 B per pixel.  A
+// pixel never leaves its lane between the three GEMMs: y stays in the accumulator registers (lane = pixel, 32 channels per
+// 32x32 tile), LayerNorm reduces over the two lanes that share a pixel, and the typed operand of the next GEMM goes through a
+// wave-private slice of the LDS image (a wave only ever reads the 64 pixel rows it wrote: no workgroup barrier inside the chain).
+// Weights: the three packed matrices (32 KB) are copied to LDS once per workgroup; a workgroup walks a contiguous range of
+// 256-pixel tiles.
+// =====================================================================================================
+struct NafTailParams {
+    const void* x;          // typed [M][64]
+    const float* a_scale;   // SCA factors [64]
+    float* stream;          // fp32 [M][64], updated in place
+    long M;
+    const void *w3, *w4, *w5;                 // pack_pointwise_weights(64 x 64), (128 x 64), (64 x 64)
+    const float *b3, *b4, *b5, *beta, *gamma, *ln_w, *ln_b;
+    float ln_eps;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void naf_tail64_kernel(const NafTailParams p) {
+    __shared__ __attribute__((aligned(16))) uint4 lds_a[2 * PW_PX * 4];        // two 32-channel chunk images of 256 pixels
+    __shared__ __attribute__((aligned(16))) uint4 lds_w[(4 + 8 + 4) * 2 * 64]; // w3: [c][ks][2 tiles], w4: [c][ks][4], w5: [c][ks][2]
+    // the per-channel vectors, read where they are used with one lane-constant LDS address + immediates (as global loads each
+    // of the 64 (vector, group) pairs wanted its own 64-bit address register pair, hoisted out of the loops: 44 spills)
+    __shared__ __attribute__((aligned(16))) float prm[9 * 64];   // b3, beta, ln_w, ln_b, b4 (128), b5, gamma, a_scale
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    {
+        const float* src[8] = {p.b3, p.beta, p.ln_w, p.ln_b, p.b4, p.b5, p.gamma, p.a_scale};
+        const int off[8] = {0, 64, 128, 192, 256, 384, 448, 512}, cnt[8] = {64, 64, 64, 64, 128, 64, 64, 64};
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (tid < cnt[k]) prm[off[k] + tid] = src[k][tid];
+    }
+    {   // weights -> LDS, fragment order as packed: [chunk][ks][tile][lane]
+        const uint4* src[3] = {reinterpret_cast<const uint4*>(p.w3), reinterpret_cast<const uint4*>(p.w4), reinterpret_cast<const uint4*>(p.w5)};
+        const int cnt[3] = {2 * 2 * 2 * 64, 2 * 2 * 4 * 64, 2 * 2 * 2 * 64}, base[3] = {0, 512, 1536};
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            for (int i = tid; i < cnt[k]; i += 256) lds_w[base[k] + i] = src[k][i];
+    }
+    __syncthreads();
+    const uint4* W3 = lds_w;
+    const uint4* W4 = lds_w + 512;
+    const uint4* W5 = lds_w + 1536;
+    const long tiles = (p.M + PW_PX - 1) / PW_PX;
+    const long t_lo = blockIdx.x * tiles / gridDim.x, t_hi = (long)(blockIdx.x + 1) * tiles / gridDim.x;
+
+    // the wave's B fragment of chunk c, k-step ks, pixel tile pt
+    auto bfrag = [&](int c, int ks, int pt) {
+        const int px = wave * 64 + pt * 32 + r;
+        return lds_a[c * (PW_PX * 4) + px * 4 + ((2 * ks + h) ^ ((px >> 2) & 3))];
+    };
+    // lane's 4 channels 32 ct + 8 g + 4 h + {0..3} of pixel `px` as typed values into the image (wave-private rows)
+    auto put4 = [&](int pt, int ct, int g, float a, float b, float c_, float d) {
+        const int px = wave * 64 + pt * 32 + r;
+        uint2* dst = reinterpret_cast<uint2*>(&lds_a[ct * (PW_PX * 4) + px * 4 + (g ^ ((px >> 2) & 3))]) + h;
+        *dst = pack4f<T>(a, b, c_, d);
+    };
+
+    for (long t = t_lo; t < t_hi; ++t) {
+        const long m0 = t * PW_PX;
+        const float* a_scale = prm + 512;
+        // ---- stage x (typed, scaled by the SCA factors) into the image: a wave stages its OWN 64 pixel rows, lane -> 16-byte slot
+        //      lane & 3 of pixels (lane >> 2) + 16 i; the lane's 16 scale factors are the same for every piece -------------------
+        float sc[2][8];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sc[c][j] = a_scale[c * 32 + (lane & 3) * 8 + j];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int px = wave * 64 + (lane >> 2) + 16 * i, sl_ = lane & 3;
+                const long m = m0 + px;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (m < p.M) {
+                    v = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.x) + m * 64 + c * 32 + sl_ * 8);
+                    float f[8];
+                    unpack8f<T>(v, f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] *= sc[c][j];
+                    v = pack8f<T>(f);
+                }
+                lds_a[c * (PW_PX * 4) + px * 4 + (sl_ ^ ((px >> 2) & 3))] = v;
+            }
+        // ---- the chain, one 32-pixel tile of the wave at a time (a rolled loop: both tiles at once need more than 256 registers) ---
+#pragma unroll 1
+        for (int pt = 0; pt < 2; ++pt) {
+            const long m = m0 + wave * 64 + pt * 32 + r;
+            // an offset the compiler cannot see through: the parameter reads stay where they are used (loop-invariant as they
+            // are, it otherwise hoists all ~200 of them out of both loops and spills)
+            int zz = 0;
+            asm volatile("" : "+v"(zz));
+            const float* pl = prm + zz;
+            const float *b3 = pl, *beta = pl + 64, *ln_w = pl + 128, *ln_b = pl + 192, *b4 = pl + 256, *b5 = pl + 384, *gamma = pl + 448;
+            // the stream row of the lane's pixel in accumulator layout: y[ct][4 g + j] = inp[px][32 ct + 8 g + 4 h + j]
+            f32x16 y[2];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (m < p.M) v = *reinterpret_cast<const f32x4*>(p.stream + m * 64 + 32 * ct + 8 * g + 4 * h);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[ct][4 * g + j] = v[j];
+                }
+            // (the image rows a wave reads are rows it wrote itself: its own LDS writes are ordered before its reads)
+            // conv3: y += (W3 . x + b3) * beta
+            {
+                f32x16 acc[2];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const uint4 xf = bfrag(c, ks, pt);
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) acc[ct] = Tr<T>::mfma(W3[((c * 2 + ks) * 2 + ct) * 64 + lane], xf, acc[ct]);
+                    }
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nn = 32 * ct + 8 * g + 4 * h;
+                        const f32x4 bb = *reinterpret_cast<const f32x4*>(b3 + nn), be = *reinterpret_cast<const f32x4*>(beta + nn);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) y[ct][4 * g + j] += (acc[ct][4 * g + j] + bb[j]) * be[j];
+                    }
+            }
+            // norm2 over the pixel's 64 channels (32 in this lane, 32 in lane ^ 32), typed into the image
+            {
+                float sum = 0.f;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sum += y[ct][i];
+                sum += __shfl_xor(sum, 32);
+                const float mean = sum * (1.f / 64.f);
+                float qq = 0.f;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float d = y[ct][i] - mean;
+                        qq += d * d;
+                    }
+                qq += __shfl_xor(qq, 32);
+                const float rstd = 1.0f / sqrtf(qq * (1.f / 64.f) + p.ln_eps);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nn = 32 * ct + 8 * g + 4 * h;
+                        const f32x4 lw = *reinterpret_cast<const f32x4*>(ln_w + nn), lb = *reinterpret_cast<const f32x4*>(ln_b + nn);
+                        float o[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = (y[ct][4 * g + j] - mean) * rstd * lw[j] + lb[j];
+                        put4(pt, ct, g, o[0], o[1], o[2], o[3]);
+                    }
+            }
+            // conv4 (128 outputs) + SimpleGate: g[n] = (a[n] + b4[n]) * (a[n + 64] + b4[n + 64]); the gated values overwrite the
+            // normalised rows once the MFMAs have consumed them
+            {
+                f32x16 acc[4];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const uint4 xf = bfrag(c, ks, pt);
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct) acc[ct] = Tr<T>::mfma(W4[((c * 2 + ks) * 4 + ct) * 64 + lane], xf, acc[ct]);
+                    }
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nn = 32 * ct + 8 * g + 4 * h;
+                        const f32x4 b1 = *reinterpret_cast<const f32x4*>(b4 + nn), b2 = *reinterpret_cast<const f32x4*>(b4 + nn + 64);
+                        float o[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = (acc[ct][4 * g + j] + b1[j]) * (acc[ct + 2][4 * g + j] + b2[j]);
+                        put4(pt, ct, g, o[0], o[1], o[2], o[3]);
+                    }
+            }
+            // conv5 + gamma residual, stream out
+            {
+                f32x16 acc[2];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const uint4 xf = bfrag(c, ks, pt);
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) acc[ct] = Tr<T>::mfma(W5[((c * 2 + ks) * 2 + ct) * 64 + lane], xf, acc[ct]);
+                    }
+                if (m < p.M) {
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int nn = 32 * ct + 8 * g + 4 * h;
+                            const f32x4 bb = *reinterpret_cast<const f32x4*>(b5 + nn), ga = *reinterpret_cast<const f32x4*>(gamma + nn);
+                            f32x4 o;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[j] = y[ct][4 * g + j] + (acc[ct][4 * g + j] + bb[j]) * ga[j];
+                            *reinterpret_cast<f32x4*>(p.stream + m * 64 + nn) = o;
+                        }
+                }
+            }
+        }
+    }
+}
+
+void launch_naf_tail64(DType dt, const void* x, const float* a_scale, float* stream, long M, const void* w3, const float* b3,
+                       const float* beta, const float* ln_w, const float* ln_b, float ln_eps, const void* w4, const float* b4,
+                       const void* w5, const float* b5, const float* gamma, hipStream_t st) {
+    NafTailParams p{x, a_scale, stream, M, w3, w4, w5, b3, b4, b5, beta, gamma, ln_w, ln_b, ln_eps};
+    const long tiles = (M + PW_PX - 1) / PW_PX;
+    // two workgroups per CU are resident (64 KB of LDS each): a grid of that many, each walking a contiguous range of tiles
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const long grid = tiles < 2L * cus ? tiles : 2L * cus;
+    if (dt == DT_BF16)
+        hipLaunchKernelGGL((naf_tail64_kernel<__bf16>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((naf_tail64_kernel<_Float16>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    FW_HIP_CHECK(hipGetLastError());
+}
+
 // Host-side packer for pointwise weights: w[cout][K] fp32 (already in the kernel's k order) ->
 // fragments [chunk][ks][cout tile][lane][8]; returns uint16 count.
 size_t pack_pointwise_weights(DType dt, const float* w, int cout, int K, uint16_t* dst) {
