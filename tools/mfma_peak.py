@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
-"""What the matrix cores sustain on random bf16 data with nothing else in the way (csrc/diag_mfma.hip): TFLOP/s and the
-clock the chip holds, for both MFMA shapes, 2 waves per SIMD on every CU.  Context for roofline.frac, which is quoted
-against the 2.5 PFLOP/s spec figure."""
-import ctypes as C, json, sys
+"""What the matrix cores sustain on random bf16 data with nothing else in the way (tools/diag/diag_mfma.hip, built here into its
+own shared object - it is a microbenchmark, not part of libframewright_hip.so): TFLOP/s and the clock the chip holds, for both
+MFMA shapes, 2 waves per SIMD on every CU.  Context for roofline.frac, which is quoted against the 2.5 PFLOP/s spec figure."""
+import ctypes as C, json, subprocess, sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
 from framewright_amd import build as B
-B.build()
-from framewright_amd import _lib
-lib = _lib.load()
+so = ROOT / "tools" / "diag" / "libdiag_mfma.so"
+subprocess.run([B.hipcc(), "-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={B.ARCH}", f"-I{B.INCLUDE}", f"-I{B.CSRC}",
+                str(ROOT / "tools" / "diag" / "diag_mfma.hip"), "-o", str(so)], check=True)
+lib = C.CDLL(str(so))
 lib.fw_debug_mfma_peak.restype = C.c_int
 lib.fw_debug_mfma_peak.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_ulonglong)]
 res = {}

@@ -16,6 +16,7 @@ Parity: oracle/rrdbnet_ref.py ``aesrgan_forward``, which is pinned on vectors th
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Dict, List, Mapping, Optional
 
 import numpy as np
@@ -62,6 +63,7 @@ class AESRGANEngine:
         self._dt = _lib.DTYPES[dtype]
         self._tdt = torch.float16 if self._dt == _lib.FW_DTYPE_F16 else torch.bfloat16
         self._dev = torch.device("cuda", self.device_id)
+        self._mu = threading.Lock()
         self._c: Dict[str, _Conv] = {}
         self._a: Dict[int, dict] = {}
 
@@ -203,7 +205,9 @@ class AESRGANEngine:
         import torch
         if not isinstance(bgr, np.ndarray) or bgr.dtype != np.uint8 or bgr.ndim != 3 or bgr.shape[2] != 3:
             raise ValueError("expected an H x W x 3 uint8 BGR image")
-        with torch.cuda.device(self._dev):
+        # one forward at a time per instance: the launches of a forward are sequenced from this thread onto the device's current
+        # stream, and a second thread on the same stream would interleave with them
+        with self._mu, torch.cuda.device(self._dev):
             x = torch.from_numpy(np.ascontiguousarray(bgr[:, :, ::-1])).to(self._dev).float() / 255.0
             y = self.forward_rgb(x).clamp_(0, 1)
             out = (y * 255.0).round().to(torch.uint8).cpu().numpy()
