@@ -9,7 +9,7 @@ from framewright_amd.realesrgan import RRDBNetEngine
 from framewright_amd.synth import synthetic_frames, synthetic_rrdbnet_state
 n_eng = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 sd = synthetic_rrdbnet_state(23, 4)
-engs = [RRDBNetEngine(23, 4, "bf16") for _ in range(n_eng)]
+engs = [RRDBNetEngine(23, 4, os.environ.get("FW_AB_DTYPE", "f16")) for _ in range(n_eng)]
 for e in engs: e.load_state_dict(sd)
 streams = [torch.cuda.Stream() for _ in range(n_eng)]
 frames = [torch.from_numpy(f).cuda() for f in synthetic_frames(4, 1080, 1920, seed=2)]

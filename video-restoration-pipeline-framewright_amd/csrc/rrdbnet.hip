@@ -57,6 +57,10 @@ struct fw_rrdbnet {
     bool split_trunk = true;
     // split trunk: lo planes only for the RRDB-level trunk (FW_RRDB_LO=0 keeps a lo plane pair behind every RDB, for A/B runs)
     bool rrdb_lo = true;
+    // TIMING-ONLY ablation (wrong pixels): bit 0 - the pair kernels, bit 1 - conv5 read every input chunk from (almost) the same
+    // plane, so their HBM reads collapse to about one plane at unchanged MACs: what a launch would cost if its inputs were
+    // already on chip (FW_RRDB_ABL_ALIAS; DESIGN.md section 6 uses it to price fusions before building them)
+    int abl_alias = 0;
     // hipGraph capture of the per-frame forward (BASELINE configs[4] "hipGraph-captured per-frame stages").  graph_mode: 0 never
     // (default), 1 always, 2 for frames of at most graph_max_px input pixels.  Off by default because it buys nothing here: the
     // launches of a forward run back to back at 1080p, and even a 48x64 frame through 3 blocks takes 0.61 ms either way (the
@@ -296,7 +300,7 @@ void forward(fw_rrdbnet* n, const void* d_in, int bits, int H, int W, void* d_ou
                     ConvPairParams q{};
                     q.in = cat[cur];
                     q.in_cstride = 32;
-                    q.in_pstride = PL;
+                    q.in_pstride = (n->abl_alias & 1) ? 40 : PL;
                     q.na = 2 + c;
                     q.H = Ht;
                     q.W = Wt;
@@ -324,6 +328,7 @@ void forward(fw_rrdbnet* n, const void* d_in, int bits, int H, int W, void* d_ou
             p.in = cat[cur];
             p.out = cat[nxt];
             p.s1 = 0.2f;
+            if (n->abl_alias & 2) p.in_pstride = 40;
             if (n->split_trunk) {
                 // y = 0.2*conv5 + x           = 0.2  * (conv5 + 5*x)            x = planes 0,1 (hi) + 6,7 (lo) of cat[cur]
                 // y = (0.2*conv5 + x)*0.2 + R = 0.04 * (conv5 + 5*x + 25*R)     R = the same planes of cat[rrdb_in]
@@ -479,6 +484,7 @@ int fw_rrdbnet_create(int device_id, int num_block, int scale, int dtype, fw_rrd
         if (const char* e = getenv("FW_RRDB_GRAPH_MAX_PX")) n->graph_max_px = atol(e);
         if (const char* e = getenv("FW_RRDB_SPLIT_TRUNK")) n->split_trunk = atoi(e) != 0;
         if (const char* e = getenv("FW_RRDB_LO")) n->rrdb_lo = atoi(e) != 0;
+        if (const char* e = getenv("FW_RRDB_ABL_ALIAS")) n->abl_alias = atoi(e);
         *out = n.release();
     });
 }
