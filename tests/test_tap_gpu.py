@@ -273,6 +273,7 @@ def test_deep_level_gemm_kernel_equals_the_staged_kernel(hip_lib, monkeypatch, H
     for mode, tail in (("1", "1"), ("0", "0")):
         monkeypatch.setenv("FW_NAF_GEMM", mode)
         monkeypatch.setenv("FW_NAF_FUSE_TAIL", tail)   # and the fused conv3..conv5 kernel of the width-64 blocks against the unfused kernels
+        monkeypatch.setenv("FW_NAF_FUSE_FRONT", tail)  # and norm1 + conv1 + depthwise conv + gate of the 64- / 128-channel blocks (pw_dw_fused.hip)
         eng = T.NAFNetEngine(dtype="f16", **FULL)
         eng.load_state_dict(sd)
         rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")

@@ -38,6 +38,9 @@ struct Block {
     DevBuf w1g, w3g, w4g, w5g;                         // the same in pack_pointwise_weights16's layout (c >= 256: the GEMM kernel)
     DevBuf wdw, bdw;                                   // depthwise fp32 [2c][9], [2c]
     DevBuf wsca, bsca;                                 // fp32 [c][c], [c]
+    DevBuf w1f, b1f, wdwt;                             // pw_dw_fused.hip (c = 64 / 128): conv1 fragments and bias with norm1 folded in, depthwise
+                                                       // filters tap-major; built by fw_nafnet_finalize from the host copies below
+    std::vector<float> h_w1, h_b1, h_n1w, h_n1b;
     unsigned have = 0;                                 // bit per tensor
 };
 constexpr unsigned BLOCK_ALL = (1u << 18) - 1;
@@ -65,6 +68,7 @@ struct fw_nafnet {
     bool fuse_ln = true;   // LayerNorm2d inside the staging pass of the GEMM that follows it at width 64 (FW_NAF_FUSE_LN=0: A/B)
     bool gemm = true;      // 1x1 convs of the levels with >= 256 channels on pointwise_gemm.hip (FW_NAF_GEMM=0: A/B)
     bool fuse_tail = true; // conv3 .. conv5 of a width-64 block as one kernel (FW_NAF_FUSE_TAIL=0: A/B)
+    bool fuse_front = true; // norm1 + conv1 + depthwise conv + gate of a 64- / 128-channel block as one kernel (FW_NAF_FUSE_FRONT=0)
 };
 
 namespace {
@@ -116,6 +120,24 @@ void upload_pointwise16(DType dt, DevBuf& b, const float* w, int cout, int K, in
     upload(b, pk.data(), pk.size() * 2);
 }
 
+// conv1 of a 64- / 128-channel block for pw_dw_fused.hip: norm1's affine part folded into the fragments and the bias
+void build_front(fw_nafnet* n, Block& bl) {
+    const int c = bl.c;
+    std::vector<uint16_t> pk(pack_pw_dw_gate_weights(n->dt, nullptr, nullptr, nullptr, nullptr, c, nullptr, nullptr));
+    std::vector<float> bf(2 * c);
+    pack_pw_dw_gate_weights(n->dt, bl.h_w1.data(), bl.h_b1.data(), bl.h_n1w.data(), bl.h_n1b.data(), c, pk.data(), bf.data());
+    upload(bl.w1f, pk.data(), pk.size() * 2);
+    upload(bl.b1f, bf.data(), bf.size() * 4);
+}
+
+// depthwise filters [channels][9] -> [9][channels]
+void upload_tap_major(DevBuf& b, const float* w, int channels) {
+    std::vector<float> t((size_t)9 * channels);
+    for (int ch = 0; ch < channels; ++ch)
+        for (int k = 0; k < 9; ++k) t[(size_t)k * channels + ch] = w[(size_t)ch * 9 + k];
+    upload(b, t.data(), t.size() * 4);
+}
+
 void upload_conv3(DType dt, DevBuf& b, const float* w, int cout, int cin) {
     const int ct = (cout + 31) / 32, ch = (cin + 31) / 32;
     std::vector<uint16_t> pk(pack_conv3x3_weights(dt, nullptr, cout, cin, ct, ch, nullptr));
@@ -160,15 +182,16 @@ void set_block_tensor(fw_nafnet* n, Block& bl, const std::string& name, const st
                       size_t numel) {
     const int c = bl.c;
     auto mark = [&](int bit) { bl.have |= 1u << bit; };
-    if (name == "norm1.weight") { need(numel, c, key); upload(bl.n1w, d, c * 4); mark(0); }
-    else if (name == "norm1.bias") { need(numel, c, key); upload(bl.n1b, d, c * 4); mark(1); }
+    const bool front = n->fuse_front && pw_dw_gate_eligible(c);
+    if (name == "norm1.weight") { need(numel, c, key); upload(bl.n1w, d, c * 4); if (front) { bl.h_n1w.assign(d, d + numel); bl.w1f.release(); } mark(0); }
+    else if (name == "norm1.bias") { need(numel, c, key); upload(bl.n1b, d, c * 4); if (front) { bl.h_n1b.assign(d, d + numel); bl.w1f.release(); } mark(1); }
     else if (name == "norm2.weight") { need(numel, c, key); upload(bl.n2w, d, c * 4); mark(2); }
     else if (name == "norm2.bias") { need(numel, c, key); upload(bl.n2b, d, c * 4); mark(3); }
     else if (name == "beta") { need(numel, c, key); upload(bl.beta, d, c * 4); mark(4); }
     else if (name == "gamma") { need(numel, c, key); upload(bl.gamma, d, c * 4); mark(5); }
-    else if (name == "conv1.weight") { need(numel, (size_t)2 * c * c, key); upload_pointwise(n->dt, bl.w1, d, 2 * c, c); if (n->gemm && c >= 256) upload_pointwise16(n->dt, bl.w1g, d, 2 * c, c, 0); mark(6); }
-    else if (name == "conv1.bias") { need(numel, 2 * c, key); upload(bl.b1, d, 2 * c * 4); mark(7); }
-    else if (name == "conv2.weight") { need(numel, (size_t)2 * c * 9, key); upload(bl.wdw, d, (size_t)2 * c * 9 * 4); mark(8); }
+    else if (name == "conv1.weight") { need(numel, (size_t)2 * c * c, key); upload_pointwise(n->dt, bl.w1, d, 2 * c, c); if (n->gemm && c >= 256) upload_pointwise16(n->dt, bl.w1g, d, 2 * c, c, 0); if (n->fuse_front && pw_dw_gate_eligible(c)) { bl.h_w1.assign(d, d + numel); bl.w1f.release(); } mark(6); }
+    else if (name == "conv1.bias") { need(numel, 2 * c, key); upload(bl.b1, d, 2 * c * 4); if (front) { bl.h_b1.assign(d, d + numel); bl.w1f.release(); } mark(7); }
+    else if (name == "conv2.weight") { need(numel, (size_t)2 * c * 9, key); upload(bl.wdw, d, (size_t)2 * c * 9 * 4); if (n->fuse_front && pw_dw_gate_eligible(c)) upload_tap_major(bl.wdwt, d, 2 * c); mark(8); }
     else if (name == "conv2.bias") { need(numel, 2 * c, key); upload(bl.bdw, d, 2 * c * 4); mark(9); }
     else if (name == "conv3.weight") { need(numel, (size_t)c * c, key); upload_pointwise(n->dt, bl.w3, d, c, c); if (n->gemm && c >= 256) upload_pointwise16(n->dt, bl.w3g, d, c, c, 0); mark(10); }
     else if (name == "conv3.bias") { need(numel, c, key); upload(bl.b3, d, c * 4); mark(11); }
@@ -224,6 +247,16 @@ void run_block(fw_nafnet* n, const Block& b, float* S, int H, int W, char* ws, c
     // inside the GEMM's staging pass
     const bool fuse_ln = c == 64 && n->fuse_ln;
     PointwiseParams p{};
+    const bool front = b.w1f.p && b.wdwt.p;
+    if (front) {
+        // norm1, conv1, the depthwise conv and the gate in one kernel: the 2c-channel tensor stays in LDS (pw_dw_fused.hip)
+        PwDwParams f{};
+        f.x = S; f.ldx = c; f.H = H; f.W = W; f.cin = c; f.ln_eps = 1e-6f;
+        f.wpk = b.w1f.p; f.bias = (const float*)b.b1f.p; f.wdw_t = (const float*)b.wdwt.p; f.bdw = (const float*)b.bdw.p;
+        f.out = T3; f.ldo = c; f.partial = csum;
+        launch_pw_dw_gate(n->dt, f, st);
+        launch_sca(csum, pw_dw_gate_blocks(H, W), M, c, (const float*)b.wsca.p, (const float*)b.bsca.p, sca, st);
+    } else {
     if (fuse_ln) {
         p.a = S; p.a_f32 = 1; p.ln_w = (const float*)b.n1w.p; p.ln_b = (const float*)b.n1b.p; p.ln_eps = 1e-6f;
     } else {
@@ -236,6 +269,7 @@ void run_block(fw_nafnet* n, const Block& b, float* S, int H, int W, char* ws, c
     // x = SimpleGate(conv2(x)); pooled sums for SCA
     launch_dwconv3x3_gate(n->dt, T2, H, W, c, (const float*)b.wdw.p, (const float*)b.bdw.p, T3, csum, st);
     launch_sca(csum, dwconv_blocks(H, W, c), M, c, (const float*)b.wsca.p, (const float*)b.bsca.p, sca, st);
+    }
     if (c == 64 && n->fuse_tail) {
         // the rest of the block in one pass over the stream (nn_ops.hip naf_tail64_kernel)
         launch_naf_tail64(n->dt, T3, sca, S, M, b.w3.p, (const float*)b.b3.p, (const float*)b.beta.p, (const float*)b.n2w.p,
@@ -347,6 +381,7 @@ int fw_nafnet_create(int device_id, int width, int middle_blk_num, const int* en
         if (const char* e = getenv("FW_NAF_FUSE_LN")) n->fuse_ln = atoi(e) != 0;
         if (const char* e = getenv("FW_NAF_GEMM")) n->gemm = atoi(e) != 0;
         if (const char* e = getenv("FW_NAF_FUSE_TAIL")) n->fuse_tail = atoi(e) != 0;
+        if (const char* e = getenv("FW_NAF_FUSE_FRONT")) n->fuse_front = atoi(e) != 0;
         n->device = device_id;
         n->dt = (DType)dtype;
         n->width = width;
@@ -444,7 +479,16 @@ int fw_nafnet_finalize(fw_nafnet* n) {
     }
     for (size_t j = 0; j < n->middle_blks.size(); ++j)
         if (n->middle_blks[j].have != BLOCK_ALL) return fail(FW_ERR_INVALID, "fw_nafnet_finalize: incomplete middle_blks." + std::to_string(j));
-    return FW_OK;
+    if (!n->fuse_front) return FW_OK;
+    return guarded([&] {
+        DevGuard dg(n->device);
+        auto each = [&](Block& bl) {
+            if (pw_dw_gate_eligible(bl.c) && !bl.w1f.p) build_front(n, bl);
+        };
+        for (auto& lv : n->encoders) for (Block& bl : lv) each(bl);
+        for (auto& lv : n->decoders) for (Block& bl : lv) each(bl);
+        for (Block& bl : n->middle_blks) each(bl);
+    });
 }
 
 int fw_nafnet_denoise_u8(fw_nafnet* n, const uint8_t* in_bgr, int in_loc, int H, int W, uint8_t* out_bgr, int out_loc,
