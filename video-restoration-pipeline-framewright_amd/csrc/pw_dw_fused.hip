@@ -38,14 +38,15 @@ __global__ __launch_bounds__(512, 2) void pw_dw_gate_kernel(const PwDwParams p) 
     constexpr int W_BYTES = NCH * KC * 4 * 1024;
     __shared__ __attribute__((aligned(16))) char ybuf[FR_Y_BYTES];
     __shared__ __attribute__((aligned(16))) uint4 wl[W_BYTES / 16];
-    __shared__ __attribute__((aligned(16))) float dwl[10 * 2 * CIN];   // depthwise filters [9][2c] + bias [2c]
+    __shared__ __attribute__((aligned(16))) float dwl[11 * 2 * CIN];   // depthwise filters [9][2c] + bias [2c], conv1 bias [2c]
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, q = lane & 15, sl = lane >> 4;
 
     for (int i = tid; i < W_BYTES / 16; i += 512) wl[i] = reinterpret_cast<const uint4*>(p.wpk)[i];
-    for (int i = tid; i < 10 * 2 * CIN; i += 512) dwl[i] = i < 9 * 2 * CIN ? p.wdw_t[i] : p.bdw[i - 9 * 2 * CIN];
+    for (int i = tid; i < 11 * 2 * CIN; i += 512)
+        dwl[i] = i < 9 * 2 * CIN ? p.wdw_t[i] : (i < 10 * 2 * CIN ? p.bdw[i - 9 * 2 * CIN] : p.bias[i - 10 * 2 * CIN]);
     __syncthreads();
 
     const int tiles_x = (p.W + FR_OC - 1) / FR_OC, tiles_y = (p.H + FR_OR - 1) / FR_OR;
@@ -61,6 +62,17 @@ __global__ __launch_bounds__(512, 2) void pw_dw_gate_kernel(const PwDwParams p) 
     f32x4 cs[NCH];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) cs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef FW_FRONT_STAMP   // diagnostic build: cycles per phase of one wave, printed at the end
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = __builtin_amdgcn_s_memtime(), t_begin = tq;
+#define FW_PH(i)                                                  \
+    do {                                                          \
+        const unsigned long long now = __builtin_amdgcn_s_memtime(); \
+        ph[i] += now - tq;                                        \
+        tq = now;                                                 \
+    } while (0)
+#else
+#define FW_PH(i)
+#endif
     const float inv_c = 1.0f / (float)CIN;
     const int C = CIN;
 
@@ -71,42 +83,56 @@ __global__ __launch_bounds__(512, 2) void pw_dw_gate_kernel(const PwDwParams p) 
         // ---- phase A: this wave's 64 halo pixels -> normalised B fragments ------------------------------------------------
         uint4 xb[4][KC];
         unsigned inside = 0;
+        constexpr int TB = CIN > 64 ? 2 : 4;          // pixel tiles whose raw fp32 is in flight together (64 registers)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int gy = ty0 - 1 + 2 * wave + (t >> 1), gx = tx0 - 1 + 16 * (t & 1) + q;
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) inside |= 1u << t;
-            const int cy = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= p.W ? p.W - 1 : gx);
-            const float* src = p.x + ((long)cy * p.W + cx) * p.ldx + 4 * sl;
-            f32x4 v[2 * KC];
+        for (int t0 = 0; t0 < 4; t0 += TB) {
+            f32x4 v[TB][2 * KC];
 #pragma unroll
-            for (int m = 0; m < 2 * KC; ++m) v[m] = *reinterpret_cast<const f32x4*>(src + 16 * m);
-            float s = 0.f;
+            for (int tt = 0; tt < TB; ++tt) {
+                const int t = t0 + tt;
+                const int gy = ty0 - 1 + 2 * wave + (t >> 1), gx = tx0 - 1 + 16 * (t & 1) + q;
+                inside |= (unsigned)(gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) << t;
+                const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
+#ifdef FW_FRONT_ABL_LOAD   // timing only: every tile reads the first tile's pixels (L2 hits)
+                const float* src = p.x + ((long)(2 * wave + (t >> 1)) * p.W + 16 * (t & 1) + q) * p.ldx + 4 * sl;
+#else
+                const float* src = p.x + ((long)cy * p.W + cx) * p.ldx + 4 * sl;
+#endif
 #pragma unroll
-            for (int m = 0; m < 2 * KC; ++m) s += (v[m][0] + v[m][1]) + (v[m][2] + v[m][3]);
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            const float mean = s * inv_c;
-            float ss = 0.f;
-#pragma unroll
-            for (int m = 0; m < 2 * KC; ++m) {
-                v[m] = v[m] - mean;
-                ss += (v[m][0] * v[m][0] + v[m][1] * v[m][1]) + (v[m][2] * v[m][2] + v[m][3] * v[m][3]);
+                for (int m = 0; m < 2 * KC; ++m) v[tt][m] = *reinterpret_cast<const f32x4*>(src + 16 * m);
             }
-            ss += __shfl_xor(ss, 16);
-            ss += __shfl_xor(ss, 32);
-            const float rstd = 1.0f / __builtin_sqrtf(ss * inv_c + p.ln_eps);
 #pragma unroll
-            for (int kc = 0; kc < KC; ++kc) {
-                uint2 h[2];
+            for (int tt = 0; tt < TB; ++tt) {
+                const int t = t0 + tt;
+                float s = 0.f;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const f32x4 n = v[2 * kc + u] * rstd;
-                    h[u] = Op<T>::pack4(n[0], n[1], n[2], n[3]);
+                for (int m = 0; m < 2 * KC; ++m) s += (v[tt][m][0] + v[tt][m][1]) + (v[tt][m][2] + v[tt][m][3]);
+                s += __shfl_xor(s, 16);
+                s += __shfl_xor(s, 32);
+                const float mean = s * inv_c;
+                float ss = 0.f;
+#pragma unroll
+                for (int m = 0; m < 2 * KC; ++m) {
+                    v[tt][m] = v[tt][m] - mean;
+                    ss += (v[tt][m][0] * v[tt][m][0] + v[tt][m][1] * v[tt][m][1]) + (v[tt][m][2] * v[tt][m][2] + v[tt][m][3] * v[tt][m][3]);
                 }
-                xb[t][kc] = make_uint4(h[0].x, h[0].y, h[1].x, h[1].y);
+                ss += __shfl_xor(ss, 16);
+                ss += __shfl_xor(ss, 32);
+                const float rstd = 1.0f / __builtin_sqrtf(ss * inv_c + p.ln_eps);
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) {
+                    uint2 h[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const f32x4 n = v[tt][2 * kc + u] * rstd;
+                        h[u] = Op<T>::pack4(n[0], n[1], n[2], n[3]);
+                    }
+                    xb[t][kc] = make_uint4(h[0].x, h[0].y, h[1].x, h[1].y);
+                }
             }
         }
 
+        FW_PH(0);
 #pragma unroll 1
         for (int j = 0; j < NCH; ++j) {
             // ---- conv1, chunk j: 64 output channels x this wave's 64 pixels ------------------------------------------------
@@ -123,12 +149,14 @@ __global__ __launch_bounds__(512, 2) void pw_dw_gate_kernel(const PwDwParams p) 
 #pragma unroll
                     for (int t = 0; t < 4; ++t) acc[t][ct] = Op<T>::mfma16(wf, xb[t][kc], acc[t][ct]);
                 }
+            FW_PH(1);
             __syncthreads();   // the depthwise pass over the previous chunk is done with ybuf
+            FW_PH(2);
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 const int cc = 16 * ct + 4 * sl;                                   // channel of the chunk
                 const int co = cc < 32 ? 32 * j + cc : C + 32 * j + (cc - 32);     // conv1 output channel
-                const f32x4 bs = *reinterpret_cast<const f32x4*>(p.bias + co);
+                const f32x4 bs = *reinterpret_cast<const f32x4*>(dwl + 10 * 2 * C + co);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     f32x4 y = acc[t][ct] + bs;
@@ -136,10 +164,13 @@ __global__ __launch_bounds__(512, 2) void pw_dw_gate_kernel(const PwDwParams p) 
                     *reinterpret_cast<uint2*>(ybuf + (64 * wave + 16 * t + q) * FR_PXB + 2 * cc) = Op<T>::pack4(y[0], y[1], y[2], y[3]);
                 }
             }
+            FW_PH(3);
             __syncthreads();
+            FW_PH(4);
 
             // ---- depthwise 3x3 + SimpleGate: channels 32 j + 4 wave .. + 3 (x1) and C + the same (x2) -----------------------
             f32x2 x1a[FR_STRIP], x1b[FR_STRIP];
+            f32x4 cj = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
             for (int half = 0; half < 2; ++half) {
 #pragma clang fp contract(fast)
@@ -164,8 +195,13 @@ __global__ __launch_bounds__(512, 2) void pw_dw_gate_kernel(const PwDwParams p) 
                 uint2 cur[3], nxt[3];
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) cur[dx] = *reinterpret_cast<const uint2*>(yh + dx * FR_PXB);
+#ifdef FW_FRONT_ABL_DW     // timing only: one input row instead of nine
+                constexpr int NR = 1;
+#else
+                constexpr int NR = FR_STRIP + 2;
+#endif
 #pragma unroll
-                for (int r = 0; r < FR_STRIP + 2; ++r) {
+                for (int r = 0; r < NR; ++r) {
                     if (r + 1 < FR_STRIP + 2) {
 #pragma unroll
                         for (int dx = 0; dx < 3; ++dx) nxt[dx] = *reinterpret_cast<const uint2*>(yh + ((r + 1) * FR_HC + dx) * FR_PXB);
@@ -194,22 +230,63 @@ __global__ __launch_bounds__(512, 2) void pw_dw_gate_kernel(const PwDwParams p) 
                         x1b[o] = ab[o];
                     }
                 } else {
+                    // The gated pixel overwrites its own x1 slot in the LDS image (this wave's channels: nobody else reads them, and
+                    // the wave's own reads are all issued) and leaves in 64-byte pieces below: eight waves x 8 bytes per pixel straight
+                    // from registers were 16 partial writes per 128-byte line (21 % of the kernel, FW_FRONT_DIRECT_STORE to compare).
                     const int gx = tx0 + col;
+#ifdef FW_FRONT_DIRECT_STORE
                     T* orow = reinterpret_cast<T*>(p.out) + 32 * j + 4 * wave;
+#endif
 #pragma unroll
                     for (int o = 0; o < FR_STRIP; ++o) {
                         const int gy = ty0 + FR_STRIP * strip + o;
                         const f32x2 ga = x1a[o] * aa[o], gb = x1b[o] * ab[o];
-                        if (dw_on && gy < p.H && gx < p.W) {
-                            *reinterpret_cast<uint2*>(orow + ((long)gy * p.W + gx) * p.ldo) = Op<T>::pack4(ga[0], ga[1], gb[0], gb[1]);
-                            cs[j] += f32x4{ga[0], ga[1], gb[0], gb[1]};
+                        const uint2 gp = Op<T>::pack4(ga[0], ga[1], gb[0], gb[1]);
+                        if (dw_on) {
+#ifndef FW_FRONT_DIRECT_STORE
+                            *reinterpret_cast<uint2*>(const_cast<char*>(yrd) + ((o + 1) * FR_HC + 1) * FR_PXB) = gp;
+#endif
+                            if (gy < p.H && gx < p.W) {
+#if defined(FW_FRONT_DIRECT_STORE) && !defined(FW_FRONT_ABL_STORE)
+                                *reinterpret_cast<uint2*>(orow + ((long)gy * p.W + gx) * p.ldo) = gp;
+#endif
+                                cj += f32x4{ga[0], ga[1], gb[0], gb[1]};
+                            }
                         }
                     }
                 }
             }
+            FW_PH(5);
+#ifndef FW_FRONT_DIRECT_STORE
+            __syncthreads();
+            FW_PH(6);
+#ifndef FW_FRONT_ABL_STORE   // timing only: no stores (the sums keep the arithmetic alive)
+#pragma unroll
+            for (int k = 0; k < (FR_OR * FR_OC * 4 + 511) / 512; ++k) {
+                const int i = tid + 512 * k;                  // (output pixel, 16-byte quarter of its 32 gated channels)
+                const int px = i >> 2, part = i & 3;
+                const int orow = px / FR_OC, ocol = px - orow * FR_OC;
+                const int gy = ty0 + orow, gx = tx0 + ocol;
+                if (px < FR_OR * FR_OC && gy < p.H && gx < p.W) {
+                    const char* src = ybuf + ((orow + 1) * FR_HC + ocol + 1) * FR_PXB + 16 * part;
+                    const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 8);
+                    store16(reinterpret_cast<T*>(p.out) + ((long)gy * p.W + gx) * p.ldo + 32 * j + 8 * part, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                }
+            }
+#endif
+#endif
+            FW_PH(7);
+#pragma unroll
+            for (int jj = 0; jj < NCH; ++jj)
+                if (jj == j) cs[jj] += cj;    // static register indices: cs[j] with a run-time j would live in scratch
         }
     }
 
+#ifdef FW_FRONT_STAMP
+    if ((blockIdx.x == 3 || blockIdx.x == 131) && lane == 0 && (wave == 0 || wave == 5))
+        printf("front c=%d wg %d wave %d tiles %ld total %llu | A %llu gemm %llu B1 %llu ywrite %llu B2 %llu dw %llu B3 %llu store %llu\n", CIN, (int)blockIdx.x,
+               wave, (long)(t_hi - t_lo), __builtin_amdgcn_s_memtime() - t_begin, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7]);
+#endif
     // ---- SCA pooling: fixed-order wave reduction of the lanes' sums -> partial[workgroup][c] ------------------------------------
     if (p.partial) {
 #pragma unroll
