@@ -155,6 +155,31 @@ def test_restormer_vs_oracle(hip_lib, dtype, max_abs, min_psnr):
     eng.close()
 
 
+@pytest.mark.parametrize("H,W", [(40, 56), (136, 200)])
+def test_fused_fronts_equal_the_staged_kernels(hip_lib, monkeypatch, H, W):
+    """LayerNorm + 1x1 + depthwise 3x3 (+ GDFN gate) of the 48- / 96-channel blocks as one kernel (pw_dw_fused.hip) against the
+    three kernels it replaces (FW_REST_FUSE_FRONT=0).  Not bit-equal: the LayerNorm's affine part is folded into the 1x1 weights and
+    the GELU's erf is a 1.5e-7 polynomial.  136 x 200 has ragged tiles in both directions and several tiles per workgroup row."""
+    sd = RS.synthetic_restormer_state(seed=5, **SMALL)
+    t = torch.from_numpy(synthetic_frames(1, H, W, seed=13)[0]).cuda()
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FW_REST_FUSE_FRONT", mode)
+        eng = RS.RestormerEngine(dtype="f16", **SMALL)
+        eng.load_state_dict(sd)
+        rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        u8 = torch.empty_like(t)
+        eng.denoise_device(t, out=u8, out_rgb_f32=rgb)
+        eng.denoise_device(t, out=u8, out_rgb_f32=rgb)      # twice: deterministic, no state left behind
+        torch.cuda.synchronize()
+        outs.append((rgb.cpu().numpy(), u8.cpu().numpy()))
+        eng.close()
+    (ra, ua), (rb, ub) = outs
+    assert np.isfinite(ra).all()
+    assert np.abs(ra - rb).max() < 1.5e-3 and np.abs(ra - rb).mean() < 3e-4      # measured 5.9e-4 / 1.0e-4: two f16 roundings apart
+    assert np.abs(ua.astype(int) - ub.astype(int)).max() <= 1
+
+
 def test_tap_denoiser_default_model_is_restormer_end_to_end(hip_lib, tmp_path, monkeypatch):
     """TAPDenoiser with the reference's default config (model = RESTORMER, tap_denoise.py:110) through the full-size
     network (4/6/6/8 + 4 blocks) with seeded weights: whole-frame and tiled paths against the oracle composed with the

@@ -163,25 +163,30 @@ void launch_pointwise_gemm(DType dt, const PointwiseParams& p, hipStream_t st);
 size_t pack_pointwise_weights16(DType dt, const float* w, int cout, int K, int gate, uint16_t* dst);
 // dst = src (pack_pointwise_weights16 layout, cout N x K) with input channel k scaled by scale[k] (NAFNet's SCA in front of conv3)
 void launch_pw16_scale_weights(DType dt, const void* src, const float* scale, int N, int K, void* dst, hipStream_t st);
-// pw_dw_fused.hip: LayerNorm2d + conv1 (c -> 2c) + depthwise 3x3 + SimpleGate of a NAFBlock in one kernel (c = 64 / 128)
+// pw_dw_fused.hip: LayerNorm + 1x1 conv + depthwise 3x3 [+ gate] in one kernel (NAFBlock front at c = 64 / 128, Restormer's
+// qkv and GDFN fronts at c = 48 / 96)
+enum PwDwMode : int {
+    PWDW_NONE = 0,       // out = dwconv(conv(norm(x))), all N channels
+    PWDW_GATE_MUL = 1,   // out[i] = dw[i] * dw[N/2 + i] (SimpleGate) + pooled sums of the output
+    PWDW_GATE_GELU = 2,  // out[i] = gelu(dw[i]) * dw[N/2 + i] (GDFN gate, exact erf GELU)
+};
 struct PwDwParams {
-    const float* x;        // fp32 NHWC stream, ldx floats per pixel
+    const float* x;        // fp32 NHWC stream, ldx floats per pixel, cin real channels
     long ldx;
     int H, W, cin;
-    float ln_eps;          // LayerNorm2d over the c channels; its affine part is folded into wpk / bias
-    const void* wpk;       // pack_pw_dw_gate_weights
-    const float* bias;     // [2c] conv1 bias + w ln_b (pack_pw_dw_gate_weights)
-    const float* wdw_t;    // [9][2c]: the depthwise filters, tap-major
-    const float* bdw;      // [2c]
-    void* out;             // typed NHWC, c gated channels, ldo elements per pixel
+    float ln_eps;          // LayerNorm over the cin channels; its affine part is folded into the parameter blocks
+    const void* blocks;    // pack_pw_dw_blocks
+    int n_chunks;          // N / 64
+    int mode;
+    void* out;             // typed NHWC, ldo elements per pixel: N channels (PWDW_NONE) or N / 2 (gate modes)
     long ldo;
-    float* partial;        // [pw_dw_gate_blocks][c] sums of the gated output for the SCA pooling, or null
+    float* partial;        // PWDW_GATE_MUL: [pw_dw_blocks][N / 2] sums of the gated output (SCA pooling), or null
 };
-bool pw_dw_gate_eligible(int cin);
-int pw_dw_gate_blocks(int H, int W);   // grid of the kernel = rows of `partial`
-void launch_pw_dw_gate(DType dt, const PwDwParams& p, hipStream_t st);
-size_t pack_pw_dw_gate_weights(DType dt, const float* w, const float* bias, const float* ln_w, const float* ln_b, int c, uint16_t* dst,
-                               float* bias_out);
+bool pw_dw_eligible(int cin, int mode);
+int pw_dw_blocks(int H, int W);   // grid of the kernel = rows of `partial`
+void launch_pw_dw(DType dt, const PwDwParams& p, hipStream_t st);
+size_t pack_pw_dw_blocks(DType dt, const float* w, const float* bias, const float* ln_w, const float* ln_b, const float* wdw, const float* bdw,
+                         int N, int c, int gate, void* dst);
 void launch_layernorm2d(DType dt, const float* x, long M, int C, const float* w, const float* b, void* out,
                         hipStream_t st);
 int dwconv_blocks(int H, int W, int C);  // grid of the dwconv kernel = rows of its `partial` output

@@ -38,9 +38,9 @@ struct Block {
     DevBuf w1g, w3g, w4g, w5g;                         // the same in pack_pointwise_weights16's layout (c >= 256: the GEMM kernel)
     DevBuf wdw, bdw;                                   // depthwise fp32 [2c][9], [2c]
     DevBuf wsca, bsca;                                 // fp32 [c][c], [c]
-    DevBuf w1f, b1f, wdwt;                             // pw_dw_fused.hip (c = 64 / 128): conv1 fragments and bias with norm1 folded in, depthwise
-                                                       // filters tap-major; built by fw_nafnet_finalize from the host copies below
-    std::vector<float> h_w1, h_b1, h_n1w, h_n1b;
+    DevBuf front;                                      // pw_dw_fused.hip (c = 64 / 128): parameter blocks of norm1 + conv1 + conv2, built by
+                                                       // fw_nafnet_finalize from the host copies below
+    std::vector<float> h_w1, h_b1, h_n1w, h_n1b, h_wdw, h_bdw;
     unsigned have = 0;                                 // bit per tensor
 };
 constexpr unsigned BLOCK_ALL = (1u << 18) - 1;
@@ -120,22 +120,12 @@ void upload_pointwise16(DType dt, DevBuf& b, const float* w, int cout, int K, in
     upload(b, pk.data(), pk.size() * 2);
 }
 
-// conv1 of a 64- / 128-channel block for pw_dw_fused.hip: norm1's affine part folded into the fragments and the bias
+// norm1 + conv1 + conv2 of a 64- / 128-channel block as parameter blocks of pw_dw_fused.hip (norm1's affine part folded into conv1)
 void build_front(fw_nafnet* n, Block& bl) {
     const int c = bl.c;
-    std::vector<uint16_t> pk(pack_pw_dw_gate_weights(n->dt, nullptr, nullptr, nullptr, nullptr, c, nullptr, nullptr));
-    std::vector<float> bf(2 * c);
-    pack_pw_dw_gate_weights(n->dt, bl.h_w1.data(), bl.h_b1.data(), bl.h_n1w.data(), bl.h_n1b.data(), c, pk.data(), bf.data());
-    upload(bl.w1f, pk.data(), pk.size() * 2);
-    upload(bl.b1f, bf.data(), bf.size() * 4);
-}
-
-// depthwise filters [channels][9] -> [9][channels]
-void upload_tap_major(DevBuf& b, const float* w, int channels) {
-    std::vector<float> t((size_t)9 * channels);
-    for (int ch = 0; ch < channels; ++ch)
-        for (int k = 0; k < 9; ++k) t[(size_t)k * channels + ch] = w[(size_t)ch * 9 + k];
-    upload(b, t.data(), t.size() * 4);
+    std::vector<char> pk(pack_pw_dw_blocks(n->dt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 2 * c, c, 1, nullptr));
+    pack_pw_dw_blocks(n->dt, bl.h_w1.data(), bl.h_b1.data(), bl.h_n1w.data(), bl.h_n1b.data(), bl.h_wdw.data(), bl.h_bdw.data(), 2 * c, c, 1, pk.data());
+    upload(bl.front, pk.data(), pk.size());
 }
 
 void upload_conv3(DType dt, DevBuf& b, const float* w, int cout, int cin) {
@@ -182,17 +172,17 @@ void set_block_tensor(fw_nafnet* n, Block& bl, const std::string& name, const st
                       size_t numel) {
     const int c = bl.c;
     auto mark = [&](int bit) { bl.have |= 1u << bit; };
-    const bool front = n->fuse_front && pw_dw_gate_eligible(c);
-    if (name == "norm1.weight") { need(numel, c, key); upload(bl.n1w, d, c * 4); if (front) { bl.h_n1w.assign(d, d + numel); bl.w1f.release(); } mark(0); }
-    else if (name == "norm1.bias") { need(numel, c, key); upload(bl.n1b, d, c * 4); if (front) { bl.h_n1b.assign(d, d + numel); bl.w1f.release(); } mark(1); }
+    const bool front = n->fuse_front && pw_dw_eligible(c, PWDW_GATE_MUL);
+    if (name == "norm1.weight") { need(numel, c, key); upload(bl.n1w, d, c * 4); if (front) { bl.h_n1w.assign(d, d + numel); bl.front.release(); } mark(0); }
+    else if (name == "norm1.bias") { need(numel, c, key); upload(bl.n1b, d, c * 4); if (front) { bl.h_n1b.assign(d, d + numel); bl.front.release(); } mark(1); }
     else if (name == "norm2.weight") { need(numel, c, key); upload(bl.n2w, d, c * 4); mark(2); }
     else if (name == "norm2.bias") { need(numel, c, key); upload(bl.n2b, d, c * 4); mark(3); }
     else if (name == "beta") { need(numel, c, key); upload(bl.beta, d, c * 4); mark(4); }
     else if (name == "gamma") { need(numel, c, key); upload(bl.gamma, d, c * 4); mark(5); }
-    else if (name == "conv1.weight") { need(numel, (size_t)2 * c * c, key); upload_pointwise(n->dt, bl.w1, d, 2 * c, c); if (n->gemm && c >= 256) upload_pointwise16(n->dt, bl.w1g, d, 2 * c, c, 0); if (n->fuse_front && pw_dw_gate_eligible(c)) { bl.h_w1.assign(d, d + numel); bl.w1f.release(); } mark(6); }
-    else if (name == "conv1.bias") { need(numel, 2 * c, key); upload(bl.b1, d, 2 * c * 4); if (front) { bl.h_b1.assign(d, d + numel); bl.w1f.release(); } mark(7); }
-    else if (name == "conv2.weight") { need(numel, (size_t)2 * c * 9, key); upload(bl.wdw, d, (size_t)2 * c * 9 * 4); if (n->fuse_front && pw_dw_gate_eligible(c)) upload_tap_major(bl.wdwt, d, 2 * c); mark(8); }
-    else if (name == "conv2.bias") { need(numel, 2 * c, key); upload(bl.bdw, d, 2 * c * 4); mark(9); }
+    else if (name == "conv1.weight") { need(numel, (size_t)2 * c * c, key); upload_pointwise(n->dt, bl.w1, d, 2 * c, c); if (n->gemm && c >= 256) upload_pointwise16(n->dt, bl.w1g, d, 2 * c, c, 0); if (front) { bl.h_w1.assign(d, d + numel); bl.front.release(); } mark(6); }
+    else if (name == "conv1.bias") { need(numel, 2 * c, key); upload(bl.b1, d, 2 * c * 4); if (front) { bl.h_b1.assign(d, d + numel); bl.front.release(); } mark(7); }
+    else if (name == "conv2.weight") { need(numel, (size_t)2 * c * 9, key); upload(bl.wdw, d, (size_t)2 * c * 9 * 4); if (front) { bl.h_wdw.assign(d, d + numel); bl.front.release(); } mark(8); }
+    else if (name == "conv2.bias") { need(numel, 2 * c, key); upload(bl.bdw, d, 2 * c * 4); if (front) { bl.h_bdw.assign(d, d + numel); bl.front.release(); } mark(9); }
     else if (name == "conv3.weight") { need(numel, (size_t)c * c, key); upload_pointwise(n->dt, bl.w3, d, c, c); if (n->gemm && c >= 256) upload_pointwise16(n->dt, bl.w3g, d, c, c, 0); mark(10); }
     else if (name == "conv3.bias") { need(numel, c, key); upload(bl.b3, d, c * 4); mark(11); }
     else if (name == "conv4.weight") { need(numel, (size_t)2 * c * c, key); upload_pointwise(n->dt, bl.w4, d, 2 * c, c); if (n->gemm && c >= 256) upload_pointwise16(n->dt, bl.w4g, d, 2 * c, c, 1); mark(12); }
@@ -247,15 +237,14 @@ void run_block(fw_nafnet* n, const Block& b, float* S, int H, int W, char* ws, c
     // inside the GEMM's staging pass
     const bool fuse_ln = c == 64 && n->fuse_ln;
     PointwiseParams p{};
-    const bool front = b.w1f.p && b.wdwt.p;
+    const bool front = b.front.p != nullptr;
     if (front) {
         // norm1, conv1, the depthwise conv and the gate in one kernel: the 2c-channel tensor stays in LDS (pw_dw_fused.hip)
         PwDwParams f{};
-        f.x = S; f.ldx = c; f.H = H; f.W = W; f.cin = c; f.ln_eps = 1e-6f;
-        f.wpk = b.w1f.p; f.bias = (const float*)b.b1f.p; f.wdw_t = (const float*)b.wdwt.p; f.bdw = (const float*)b.bdw.p;
+        f.x = S; f.ldx = c; f.H = H; f.W = W; f.cin = c; f.ln_eps = 1e-6f; f.blocks = b.front.p; f.n_chunks = 2 * c / 64; f.mode = PWDW_GATE_MUL;
         f.out = T3; f.ldo = c; f.partial = csum;
-        launch_pw_dw_gate(n->dt, f, st);
-        launch_sca(csum, pw_dw_gate_blocks(H, W), M, c, (const float*)b.wsca.p, (const float*)b.bsca.p, sca, st);
+        launch_pw_dw(n->dt, f, st);
+        launch_sca(csum, pw_dw_blocks(H, W), M, c, (const float*)b.wsca.p, (const float*)b.bsca.p, sca, st);
     } else {
     if (fuse_ln) {
         p.a = S; p.a_f32 = 1; p.ln_w = (const float*)b.n1w.p; p.ln_b = (const float*)b.n1b.p; p.ln_eps = 1e-6f;
@@ -483,7 +472,7 @@ int fw_nafnet_finalize(fw_nafnet* n) {
     return guarded([&] {
         DevGuard dg(n->device);
         auto each = [&](Block& bl) {
-            if (pw_dw_gate_eligible(bl.c) && !bl.w1f.p) build_front(n, bl);
+            if (pw_dw_eligible(bl.c, PWDW_GATE_MUL) && !bl.front.p) build_front(n, bl);
         };
         for (auto& lv : n->encoders) for (Block& bl : lv) each(bl);
         for (auto& lv : n->decoders) for (Block& bl : lv) each(bl);

@@ -1,23 +1,28 @@
-// LayerNorm -> 1x1 convolution -> depthwise 3x3 -> gate in one kernel: the first half of a NAFBlock at the wide levels
-// (reference: the NAFNet the TAP driver loads, tap_denoise.py:299-333; block layout as in oracle/nafnet_ref.py).
+// LayerNorm -> 1x1 convolution -> depthwise 3x3 [-> gate] in one kernel:
+//   * the first half of a NAFBlock (norm1, conv1 c -> 2c, conv2 depthwise, SimpleGate x1 * x2, pooled sums for the SCA) at the
+//     64- and 128-channel levels (reference: the NAFNet the TAP driver loads, tap_denoise.py:299-333; oracle/nafnet_ref.py);
+//   * Restormer's two depthwise stages (tap_denoise.py:299-333 loads it as the default TAP model; oracle/restormer_ref.py):
+//     norm1 -> qkv 1x1 -> qkv_dwconv (MDTA), and norm2 -> project_in -> dwconv -> gelu(x1) * x2 (GDFN), at 48 and 96 channels.
 //
-// Unfused, the 2c-channel tensor between conv1 and the depthwise conv is written and read once each (512 of the 1536 bytes a
-// width-64 block moved per pixel) and the depthwise kernel itself ran at 2.1 TB/s (three overlapping 16-byte gathers per
-// tap column through the texture path).  Here that tensor only exists in LDS:
+// Unfused, the wide tensor between the 1x1 and the depthwise convolution is written and read once each (the largest tensor of
+// either block: 2c, 3c or 5.3c channels) and the depthwise kernels gathered it at 2 TB/s.  Here it only exists in LDS:
 //
-//   * a persistent 512-thread workgroup walks 14 x 30-pixel output tiles; conv1 is evaluated on the 16 x 32 halo tile
+//   * a persistent 512-thread workgroup walks 14 x 30-pixel output tiles; the 1x1 conv is evaluated on the 16 x 32 halo tile
 //     (x1.22 MACs - they are cheap: K = c);
 //   * phase A: wave w loads the fp32 stream of halo rows 2w, 2w+1 straight into registers (lane = pixel l & 15, quarter
-//     l >> 4 of every 16-channel group: each load instruction covers 64 contiguous bytes per pixel), LayerNorm2d statistics
+//     l >> 4 of every 16-channel group: each load instruction covers 64 contiguous bytes per pixel), LayerNorm statistics
 //     with two xor-shuffles, (x - mean) * rstd becomes the B fragments of v_mfma_f32_16x16x32 (c / 2 registers); the affine
-//     part of the LayerNorm is folded into conv1 by the host (W' = W diag(gamma), b' = b + W beta: pack_pw_dw_gate_weights);
-//   * per chunk of 64 conv1 channels (32 x1 channels and the 32 x2 channels they are gated with): the GEMM from LDS-resident
-//     weight fragments into 16 accumulator tiles, + bias, zero outside the image (the depthwise conv pads conv1's OUTPUT),
-//     typed, into a [512 px][136 B] LDS image (stride 34 dwords: 16 lanes of consecutive pixels cover all 32 banks);
-//   * depthwise 3x3 + SimpleGate from LDS: wave w owns channels 4w..4w+3 of the chunk's 32 pairs, so its 72 + 8 filter taps
-//     and biases are wave-uniform (SGPRs); lane = (7-row strip, column); 27 ds_read_b64 per half feed 63 x 2 v_pk_fma_f32;
-//     the gated pixels go to HBM as 8-byte stores, their sums stay in registers for the SCA pooling
-//     (wave reduction at the end of the kernel -> partial[workgroup][c], the fixed-order scheme of dwconv3x3_gate_kernel).
+//     part of the LayerNorm is folded into the 1x1 conv by the host (W' = W diag(gamma), b' = b + W beta: pack_pw_dw_blocks);
+//   * the 1x1 conv's output channels are processed in chunks of 64 (gate modes: 32 x1 channels and the 32 x2 channels they are
+//     gated with).  A chunk's parameters - weight fragments, conv bias, depthwise taps and bias - are one contiguous block
+//     that arrives by LDS-DMA while the previous chunk is in its depthwise phase (two buffers);
+//   * per chunk: the GEMM into 16 accumulator tiles, + bias, zero outside the image (the depthwise conv pads the 1x1 conv's
+//     OUTPUT), typed, into a [512 px][136 B] LDS image (stride 34 dwords: 16 lanes of consecutive pixels cover all 32 banks);
+//   * depthwise 3x3 from LDS: wave w owns channels 4w..4w+3 of each half of the chunk, so its filter taps are wave-uniform;
+//     lane = (7-row strip, column); 27 ds_read_b64 per half feed 63 x 2 v_pk_fma_f32, one input row ahead of the FMAs;
+//   * the result overwrites the wave's own slots of the LDS image and leaves in 16-byte pieces, 64 (gate) or 128 contiguous
+//     bytes per pixel; the SimpleGate sums stay in registers for the SCA pooling (wave reduction at the end of the kernel ->
+//     partial[workgroup][c], the fixed-order scheme of dwconv3x3_gate_kernel).
 #include "fw_internal.h"
 #include "conv_common.h"
 
@@ -28,53 +33,79 @@ constexpr int FR_OR = 14, FR_OC = 30;                 // output tile
 constexpr int FR_PXB = 136;                           // LDS bytes per pixel record: 64 channels + 8 pad
 constexpr int FR_Y_BYTES = FR_HR * FR_HC * FR_PXB;    // 69632
 constexpr int FR_STRIP = 7;                           // output rows per depthwise item
+constexpr int FR_TAIL = 11 * 64 * 4;                  // per chunk: depthwise taps [9][64], depthwise bias [64], conv bias [64] (fp32)
+
+constexpr int pw_dw_block_bytes(int kc) { return (kc * 4096 + FR_TAIL + 1023) / 1024 * 1024; }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <typename T, int CIN>
-__global__ __launch_bounds__(512, 2) void pw_dw_gate_kernel(const PwDwParams p) {
-    constexpr int KC = CIN / 32;                      // 32-channel chunks of the contraction
-    constexpr int NCH = 2 * CIN / 64;                 // 64-channel chunks of conv1's output
-    constexpr int W_BYTES = NCH * KC * 4 * 1024;
+// erf after Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7): the GDFN gate's exact GELU at a third of erff's instructions
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float ax = __builtin_fabsf(x);
+    const float z = ax * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    float q = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    q = __builtin_fmaf(q, t, 1.421413741f);
+    q = __builtin_fmaf(q, t, -0.284496736f);
+    q = __builtin_fmaf(q, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+    const float erf_abs = __builtin_fmaf(-q * t, e, 1.0f);
+    // 0.5 x (1 + erf(x / sqrt 2)) = 0.5 (x + |x| erf(|x| / sqrt 2))
+    return 0.5f * __builtin_fmaf(ax, erf_abs, x);
+}
+
+// CG: 16-channel groups of the input (c = 16 CG); MODE: PWDW_NONE / PWDW_GATE_MUL / PWDW_GATE_GELU
+template <typename T, int CG, int MODE>
+__global__ __launch_bounds__(512, 2) void pw_dw_kernel(const PwDwParams p) {
+    constexpr int KC = (CG + 1) / 2;                  // 32-channel chunks of the contraction (the last one half empty when CG is odd)
+    constexpr int PB = pw_dw_block_bytes(KC);         // bytes of a chunk's parameter block
+    constexpr int NPIECE = PB / 1024;
+    constexpr bool GATE = MODE != PWDW_NONE;
+    constexpr int OUT_B = GATE ? 64 : 128;            // output bytes per pixel and chunk
     __shared__ __attribute__((aligned(16))) char ybuf[FR_Y_BYTES];
-    __shared__ __attribute__((aligned(16))) uint4 wl[W_BYTES / 16];
-    __shared__ __attribute__((aligned(16))) float dwl[11 * 2 * CIN];   // depthwise filters [9][2c] + bias [2c], conv1 bias [2c]
+    __shared__ __attribute__((aligned(16))) char pbuf[2 * PB];
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, q = lane & 15, sl = lane >> 4;
+    const unsigned pb_lds = (unsigned)(size_t)(lds_ptr_t)pbuf;
+    const char* blocks = reinterpret_cast<const char*>(p.blocks);
+    const int nch = p.n_chunks;
 
-    for (int i = tid; i < W_BYTES / 16; i += 512) wl[i] = reinterpret_cast<const uint4*>(p.wpk)[i];
-    for (int i = tid; i < 11 * 2 * CIN; i += 512)
-        dwl[i] = i < 9 * 2 * CIN ? p.wdw_t[i] : (i < 10 * 2 * CIN ? p.bdw[i - 9 * 2 * CIN] : p.bias[i - 10 * 2 * CIN]);
-    __syncthreads();
+    auto fetch = [&](int chunk, int buf) {            // this wave's pieces of a parameter block
+        for (int i = wave; i < NPIECE; i += 8)
+            glds16(blocks + (size_t)chunk * PB + i * 1024, lane * 16, pb_lds + buf * PB + i * 1024);
+    };
 
     const int tiles_x = (p.W + FR_OC - 1) / FR_OC, tiles_y = (p.H + FR_OR - 1) / FR_OR;
     const long ntiles = (long)tiles_x * tiles_y;
     const long t_lo = blockIdx.x * ntiles / gridDim.x, t_hi = (long)(blockIdx.x + 1) * ntiles / gridDim.x;
+    if (t_lo >= t_hi) return;
+    fetch(0, 0);
 
     // depthwise item of this lane: strip (0/1) and column; lanes 60-63 idle
     const bool dw_on = lane < 2 * FR_OC;
     const int strip = lane >= FR_OC ? 1 : 0;
     const int col = dw_on ? lane - strip * FR_OC : 0;
-    const char* yrd = ybuf + ((FR_STRIP * strip) * FR_HC + col) * FR_PXB + 8 * wave;
+    char* yrd = ybuf + ((FR_STRIP * strip) * FR_HC + col) * FR_PXB + 8 * wave;
 
-    f32x4 cs[NCH];
+    f32x4 cs[4];                                      // PWDW_GATE_MUL: pooled sums of up to four chunks (c <= 128)
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) cs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j) cs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float inv_c = 1.0f / (float)(16 * CG);
+    unsigned g = 0;                                   // chunks done: parameter buffer = g & 1
+
 #ifdef FW_FRONT_STAMP   // diagnostic build: cycles per phase of one wave, printed at the end
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = __builtin_amdgcn_s_memtime(), t_begin = tq;
-#define FW_PH(i)                                                  \
-    do {                                                          \
+#define FW_PH(i)                                                     \
+    do {                                                             \
         const unsigned long long now = __builtin_amdgcn_s_memtime(); \
-        ph[i] += now - tq;                                        \
-        tq = now;                                                 \
+        ph[i] += now - tq;                                           \
+        tq = now;                                                    \
     } while (0)
 #else
 #define FW_PH(i)
 #endif
-    const float inv_c = 1.0f / (float)CIN;
-    const int C = CIN;
 
     for (long tile = t_lo; tile < t_hi; ++tile) {
         const int tyi = (int)(tile / tiles_x);
@@ -83,10 +114,10 @@ __global__ __launch_bounds__(512, 2) void pw_dw_gate_kernel(const PwDwParams p) 
         // ---- phase A: this wave's 64 halo pixels -> normalised B fragments ------------------------------------------------
         uint4 xb[4][KC];
         unsigned inside = 0;
-        constexpr int TB = CIN > 64 ? 2 : 4;          // pixel tiles whose raw fp32 is in flight together (64 registers)
+        constexpr int TB = CG > 4 ? 2 : 4;            // pixel tiles whose raw fp32 is in flight together (<= 64 registers)
 #pragma unroll
         for (int t0 = 0; t0 < 4; t0 += TB) {
-            f32x4 v[TB][2 * KC];
+            f32x4 v[TB][CG];
 #pragma unroll
             for (int tt = 0; tt < TB; ++tt) {
                 const int t = t0 + tt;
@@ -99,20 +130,20 @@ __global__ __launch_bounds__(512, 2) void pw_dw_gate_kernel(const PwDwParams p) 
                 const float* src = p.x + ((long)cy * p.W + cx) * p.ldx + 4 * sl;
 #endif
 #pragma unroll
-                for (int m = 0; m < 2 * KC; ++m) v[tt][m] = *reinterpret_cast<const f32x4*>(src + 16 * m);
+                for (int m = 0; m < CG; ++m) v[tt][m] = *reinterpret_cast<const f32x4*>(src + 16 * m);
             }
 #pragma unroll
             for (int tt = 0; tt < TB; ++tt) {
                 const int t = t0 + tt;
                 float s = 0.f;
 #pragma unroll
-                for (int m = 0; m < 2 * KC; ++m) s += (v[tt][m][0] + v[tt][m][1]) + (v[tt][m][2] + v[tt][m][3]);
+                for (int m = 0; m < CG; ++m) s += (v[tt][m][0] + v[tt][m][1]) + (v[tt][m][2] + v[tt][m][3]);
                 s += __shfl_xor(s, 16);
                 s += __shfl_xor(s, 32);
                 const float mean = s * inv_c;
                 float ss = 0.f;
 #pragma unroll
-                for (int m = 0; m < 2 * KC; ++m) {
+                for (int m = 0; m < CG; ++m) {
                     v[tt][m] = v[tt][m] - mean;
                     ss += (v[tt][m][0] * v[tt][m][0] + v[tt][m][1] * v[tt][m][1]) + (v[tt][m][2] * v[tt][m][2] + v[tt][m][3] * v[tt][m][3]);
                 }
@@ -124,39 +155,52 @@ __global__ __launch_bounds__(512, 2) void pw_dw_gate_kernel(const PwDwParams p) 
                     uint2 h[2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        const f32x4 n = v[tt][2 * kc + u] * rstd;
-                        h[u] = Op<T>::pack4(n[0], n[1], n[2], n[3]);
+                        if (2 * kc + u < CG) {
+                            const f32x4 n = v[tt][2 * kc + u] * rstd;
+                            h[u] = Op<T>::pack4(n[0], n[1], n[2], n[3]);
+                        } else {
+                            h[u] = make_uint2(0u, 0u);       // K padding of an odd group count: zero activations on zero weights
+                        }
                     }
                     xb[t][kc] = make_uint4(h[0].x, h[0].y, h[1].x, h[1].y);
                 }
             }
         }
-
         FW_PH(0);
+
 #pragma unroll 1
-        for (int j = 0; j < NCH; ++j) {
-            // ---- conv1, chunk j: 64 output channels x this wave's 64 pixels ------------------------------------------------
+        for (int j = 0; j < nch; ++j, ++g) {
+            const char* pb = pbuf + (g & 1) * PB;
+            const float* tail = reinterpret_cast<const float*>(pb + KC * 4096);   // [9][64] taps, [64] depthwise bias, [64] conv bias
+            // the chunk's parameters have landed (each wave waits for its own DMAs, then the barrier); the same barrier says the
+            // previous chunk's store phase is done with ybuf
+            FW_WAIT_VMCNT(0);
+            __syncthreads();
+            FW_PH(2);
+            {   // next chunk's parameters (cyclic over the tiles of this workgroup)
+                const bool last = j + 1 == nch;
+                if (!(last && tile + 1 == t_hi)) fetch(last ? 0 : j + 1, (int)((g + 1) & 1));
+            }
+            // ---- 1x1 conv, chunk j: 64 output channels x this wave's 64 pixels -----------------------------------------------
             f32x4 acc[4][4];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) acc[t][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const uint4* wl = reinterpret_cast<const uint4*>(pb) + lane;
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) {
-                    const uint4 wf = wl[((j * KC + kc) * 4 + ct) * 64 + lane];
+                    const uint4 wf = wl[(kc * 4 + ct) * 64];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) acc[t][ct] = Op<T>::mfma16(wf, xb[t][kc], acc[t][ct]);
                 }
             FW_PH(1);
-            __syncthreads();   // the depthwise pass over the previous chunk is done with ybuf
-            FW_PH(2);
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 const int cc = 16 * ct + 4 * sl;                                   // channel of the chunk
-                const int co = cc < 32 ? 32 * j + cc : C + 32 * j + (cc - 32);     // conv1 output channel
-                const f32x4 bs = *reinterpret_cast<const f32x4*>(dwl + 10 * 2 * C + co);
+                const f32x4 bs = *reinterpret_cast<const f32x4*>(tail + 10 * 64 + cc);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     f32x4 y = acc[t][ct] + bs;
@@ -168,21 +212,21 @@ __global__ __launch_bounds__(512, 2) void pw_dw_gate_kernel(const PwDwParams p) 
             __syncthreads();
             FW_PH(4);
 
-            // ---- depthwise 3x3 + SimpleGate: channels 32 j + 4 wave .. + 3 (x1) and C + the same (x2) -----------------------
+            // ---- depthwise 3x3 [+ gate]: chunk channels 4 wave .. + 3 (half 0) and 32 + the same (half 1) -------------------
             f32x2 x1a[FR_STRIP], x1b[FR_STRIP];
             f32x4 cj = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
             for (int half = 0; half < 2; ++half) {
 #pragma clang fp contract(fast)
-                const int ch0 = half * C + 32 * j + 4 * wave;
+                const int ch0 = 32 * half + 4 * wave;
                 f32x2 wa[9], wb[9];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(dwl + k * 2 * C + ch0);
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(tail + k * 64 + ch0);
                     wa[k] = f32x2{wv[0], wv[1]};
                     wb[k] = f32x2{wv[2], wv[3]};
                 }
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(dwl + 9 * 2 * C + ch0);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(tail + 9 * 64 + ch0);
                 const f32x2 ba = {bv[0], bv[1]}, bb = {bv[2], bv[3]};
                 f32x2 aa[FR_STRIP], ab[FR_STRIP];
 #pragma unroll
@@ -191,7 +235,7 @@ __global__ __launch_bounds__(512, 2) void pw_dw_gate_kernel(const PwDwParams p) 
                     ab[o] = bb;
                 }
                 // one input row ahead of the FMAs; the scheduling barriers keep hipcc from hoisting all 27 reads (54 registers)
-                const char* yh = yrd + 64 * half;
+                char* yh = yrd + 64 * half;
                 uint2 cur[3], nxt[3];
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) cur[dx] = *reinterpret_cast<const uint2*>(yh + dx * FR_PXB);
@@ -223,80 +267,85 @@ __global__ __launch_bounds__(512, 2) void pw_dw_gate_kernel(const PwDwParams p) 
                     for (int dx = 0; dx < 3; ++dx) cur[dx] = nxt[dx];
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (half == 0) {
+                // The result overwrites the wave's own slot of the LDS image (this wave's channels: nobody else reads them, and
+                // the wave's own reads are all issued) and leaves in 16-byte pieces below: 8-byte stores of eight waves straight
+                // from registers were 16 partial writes per 128-byte line.
+                if (GATE && half == 0) {
 #pragma unroll
                     for (int o = 0; o < FR_STRIP; ++o) {
-                        x1a[o] = aa[o];
-                        x1b[o] = ab[o];
+                        if constexpr (MODE == PWDW_GATE_GELU) {
+                            x1a[o] = f32x2{gelu_erf(aa[o][0]), gelu_erf(aa[o][1])};
+                            x1b[o] = f32x2{gelu_erf(ab[o][0]), gelu_erf(ab[o][1])};
+                        } else {
+                            x1a[o] = aa[o];
+                            x1b[o] = ab[o];
+                        }
                     }
                 } else {
-                    // The gated pixel overwrites its own x1 slot in the LDS image (this wave's channels: nobody else reads them, and
-                    // the wave's own reads are all issued) and leaves in 64-byte pieces below: eight waves x 8 bytes per pixel straight
-                    // from registers were 16 partial writes per 128-byte line (21 % of the kernel, FW_FRONT_DIRECT_STORE to compare).
                     const int gx = tx0 + col;
-#ifdef FW_FRONT_DIRECT_STORE
-                    T* orow = reinterpret_cast<T*>(p.out) + 32 * j + 4 * wave;
-#endif
 #pragma unroll
                     for (int o = 0; o < FR_STRIP; ++o) {
                         const int gy = ty0 + FR_STRIP * strip + o;
-                        const f32x2 ga = x1a[o] * aa[o], gb = x1b[o] * ab[o];
-                        const uint2 gp = Op<T>::pack4(ga[0], ga[1], gb[0], gb[1]);
+                        f32x2 ga = aa[o], gb = ab[o];
+                        if constexpr (GATE) {
+                            ga = x1a[o] * ga;
+                            gb = x1b[o] * gb;
+                        }
                         if (dw_on) {
-#ifndef FW_FRONT_DIRECT_STORE
-                            *reinterpret_cast<uint2*>(const_cast<char*>(yrd) + ((o + 1) * FR_HC + 1) * FR_PXB) = gp;
-#endif
-                            if (gy < p.H && gx < p.W) {
-#if defined(FW_FRONT_DIRECT_STORE) && !defined(FW_FRONT_ABL_STORE)
-                                *reinterpret_cast<uint2*>(orow + ((long)gy * p.W + gx) * p.ldo) = gp;
-#endif
-                                cj += f32x4{ga[0], ga[1], gb[0], gb[1]};
-                            }
+                            *reinterpret_cast<uint2*>(yrd + (GATE ? 0 : 64 * half) + ((o + 1) * FR_HC + 1) * FR_PXB) = Op<T>::pack4(ga[0], ga[1], gb[0], gb[1]);
+                            if (MODE == PWDW_GATE_MUL && gy < p.H && gx < p.W) cj += f32x4{ga[0], ga[1], gb[0], gb[1]};
                         }
                     }
                 }
             }
             FW_PH(5);
-#ifndef FW_FRONT_DIRECT_STORE
             __syncthreads();
             FW_PH(6);
 #ifndef FW_FRONT_ABL_STORE   // timing only: no stores (the sums keep the arithmetic alive)
+            {
+                constexpr int PPX = OUT_B / 16;               // 16-byte pieces per pixel
+                T* obase = reinterpret_cast<T*>(p.out) + (OUT_B / 2) * j;
 #pragma unroll
-            for (int k = 0; k < (FR_OR * FR_OC * 4 + 511) / 512; ++k) {
-                const int i = tid + 512 * k;                  // (output pixel, 16-byte quarter of its 32 gated channels)
-                const int px = i >> 2, part = i & 3;
-                const int orow = px / FR_OC, ocol = px - orow * FR_OC;
-                const int gy = ty0 + orow, gx = tx0 + ocol;
-                if (px < FR_OR * FR_OC && gy < p.H && gx < p.W) {
-                    const char* src = ybuf + ((orow + 1) * FR_HC + ocol + 1) * FR_PXB + 16 * part;
-                    const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 8);
-                    store16(reinterpret_cast<T*>(p.out) + ((long)gy * p.W + gx) * p.ldo + 32 * j + 8 * part, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                for (int k = 0; k < (FR_OR * FR_OC * PPX + 511) / 512; ++k) {
+                    const int i = tid + 512 * k;              // (output pixel, piece)
+                    const int px = i / PPX, part = i - px * PPX;
+                    const int orow = px / FR_OC, ocol = px - orow * FR_OC;
+                    const int gy = ty0 + orow, gx = tx0 + ocol;
+                    if (px < FR_OR * FR_OC && gy < p.H && gx < p.W) {
+                        const char* src = ybuf + ((orow + 1) * FR_HC + ocol + 1) * FR_PXB + 16 * part;
+                        const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 8);
+                        store16(obase + ((long)gy * p.W + gx) * p.ldo + 8 * part, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                    }
                 }
             }
 #endif
-#endif
             FW_PH(7);
+            if constexpr (MODE == PWDW_GATE_MUL) {
 #pragma unroll
-            for (int jj = 0; jj < NCH; ++jj)
-                if (jj == j) cs[jj] += cj;    // static register indices: cs[j] with a run-time j would live in scratch
+                for (int jj = 0; jj < 4; ++jj)
+                    if (jj == j) cs[jj] += cj;    // static register indices: cs[j] with a run-time j would live in scratch
+            }
         }
     }
 
 #ifdef FW_FRONT_STAMP
     if ((blockIdx.x == 3 || blockIdx.x == 131) && lane == 0 && (wave == 0 || wave == 5))
-        printf("front c=%d wg %d wave %d tiles %ld total %llu | A %llu gemm %llu B1 %llu ywrite %llu B2 %llu dw %llu B3 %llu store %llu\n", CIN, (int)blockIdx.x,
-               wave, (long)(t_hi - t_lo), __builtin_amdgcn_s_memtime() - t_begin, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7]);
+        printf("front cg=%d mode %d wg %d wave %d tiles %ld total %llu | A %llu gemm %llu B1 %llu ywrite %llu B2 %llu dw %llu B3 %llu store %llu\n", CG, MODE,
+               (int)blockIdx.x, wave, (long)(t_hi - t_lo), __builtin_amdgcn_s_memtime() - t_begin, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7]);
 #endif
     // ---- SCA pooling: fixed-order wave reduction of the lanes' sums -> partial[workgroup][c] ------------------------------------
-    if (p.partial) {
+    if constexpr (MODE == PWDW_GATE_MUL) {
+        if (p.partial) {
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            f32x4 v = cs[j];
+            for (int j = 0; j < 4; ++j) {
+                if (j >= nch) break;
+                f32x4 v = cs[j];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1)
+                for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] += __shfl_xor(v[i], o);
-            if (lane == 0) *reinterpret_cast<f32x4*>(p.partial + (long)blockIdx.x * C + 32 * j + 4 * wave) = v;
+                    for (int i = 0; i < 4; ++i) v[i] += __shfl_xor(v[i], o);
+                if (lane == 0) *reinterpret_cast<f32x4*>(p.partial + (long)blockIdx.x * (32 * nch) + 32 * j + 4 * wave) = v;
+            }
         }
     }
 }
@@ -311,57 +360,81 @@ static int front_cus() {
     return n;
 }
 
-int pw_dw_gate_blocks(int H, int W) {
+int pw_dw_blocks(int H, int W) {
     const long tiles = (long)((H + FR_OR - 1) / FR_OR) * ((W + FR_OC - 1) / FR_OC);
     return (int)(tiles < front_cus() ? tiles : front_cus());
 }
 
-bool pw_dw_gate_eligible(int cin) { return cin == 64 || cin == 128; }
+bool pw_dw_eligible(int cin, int mode) {
+    if (mode == PWDW_GATE_MUL) return cin == 64 || cin == 128;
+    if (mode == PWDW_NONE || mode == PWDW_GATE_GELU) return cin == 48 || cin == 96;
+    return false;
+}
 
-void launch_pw_dw_gate(DType dt, const PwDwParams& p, hipStream_t st) {
-    if (!pw_dw_gate_eligible(p.cin) || p.H <= 0 || p.W <= 0 || (p.ldx % 4) || (p.ldo % 4) || !p.x || !p.wpk || !p.bias || !p.wdw_t || !p.bdw || !p.out)
-        throw Error(1, "pw_dw_gate: shape not eligible");
-    dim3 grid((unsigned)pw_dw_gate_blocks(p.H, p.W)), block(512);
-#define FW_F(CIN)                                                                                     \
-    do {                                                                                              \
-        if (dt == DT_BF16)                                                                            \
-            hipLaunchKernelGGL((pw_dw_gate_kernel<__bf16, CIN>), grid, block, 0, st, p);              \
-        else                                                                                          \
-            hipLaunchKernelGGL((pw_dw_gate_kernel<_Float16, CIN>), grid, block, 0, st, p);            \
+void launch_pw_dw(DType dt, const PwDwParams& p, hipStream_t st) {
+    if (!pw_dw_eligible(p.cin, p.mode) || p.H <= 0 || p.W <= 0 || (p.ldx % 4) || (p.ldo % 8) || !p.x || !p.blocks || !p.out || p.n_chunks < 1 ||
+        (p.mode == PWDW_GATE_MUL && p.n_chunks > 4))
+        throw Error(1, "pw_dw: shape not eligible");
+    dim3 grid((unsigned)pw_dw_blocks(p.H, p.W)), block(512);
+#define FW_F(CG, MODE)                                                                            \
+    do {                                                                                          \
+        if (dt == DT_BF16)                                                                        \
+            hipLaunchKernelGGL((pw_dw_kernel<__bf16, CG, MODE>), grid, block, 0, st, p);          \
+        else                                                                                      \
+            hipLaunchKernelGGL((pw_dw_kernel<_Float16, CG, MODE>), grid, block, 0, st, p);        \
     } while (0)
-    if (p.cin == 64) FW_F(64);
-    else FW_F(128);
+    if (p.mode == PWDW_GATE_MUL) {
+        if (p.cin == 64) FW_F(4, PWDW_GATE_MUL);
+        else FW_F(8, PWDW_GATE_MUL);
+    } else if (p.mode == PWDW_NONE) {
+        if (p.cin == 48) FW_F(3, PWDW_NONE);
+        else FW_F(6, PWDW_NONE);
+    } else {
+        if (p.cin == 48) FW_F(3, PWDW_GATE_GELU);
+        else FW_F(6, PWDW_GATE_GELU);
+    }
 #undef FW_F
     FW_HIP_CHECK(hipGetLastError());
 }
 
-// Host-side packer: conv1 weights w[2c][c] fp32 with the LayerNorm's affine part folded in (w' = w * ln_w[k]) ->
-// [64-channel chunk j][32-channel K chunk][16-row tile (4)][lane][8], the A operand of v_mfma_f32_16x16x32.  Chunk j holds x1
-// channels 32j..32j+31 (tiles 0, 1) and the x2 channels c + 32j.. they are gated with (tiles 2, 3).  K order inside a
-// fragment: element e of lane l is channel 32 kc + 16 (e >> 2) + 4 (l >> 4) + (e & 3) - the order in which the kernel's
-// 16-byte loads of the fp32 stream land in its B fragments.  bias_out[2c] = bias + w ln_b.
-size_t pack_pw_dw_gate_weights(DType dt, const float* w, const float* bias, const float* ln_w, const float* ln_b, int c, uint16_t* dst,
-                               float* bias_out) {
-    const int nch = 2 * c / 64, kcs = c / 32;
-    const size_t n = (size_t)nch * kcs * 4 * 64 * 8;
-    if (!dst) return n;
-    size_t o = 0;
-    for (int j = 0; j < nch; ++j)
+// Host-side packer.  w[N][c] fp32 (1x1 conv rows in the layout of the output tensor: N a multiple of 64; gate modes: x1 rows at
+// 0, x2 rows at N / 2), bias[N] or null, LayerNorm weight / bias [c], depthwise filters wdw[N][9] and bias bdw[N] or null.
+// Output: N / 64 parameter blocks of pw_dw_block_bytes((c / 16 + 1) / 2) bytes:
+//   [K chunk][16-row tile (4)][lane][8] operand-typed A fragments of v_mfma_f32_16x16x32 with the LayerNorm weight folded in
+//   (w' = w * ln_w[k]); K order inside a fragment: element e of lane l is channel 32 kc + 16 (e >> 2) + 4 (l >> 4) + (e & 3) - the
+//   order in which the kernel's 16-byte loads of the fp32 stream land in its B fragments; channels >= c are zero;
+//   then fp32 [9][64] depthwise taps, [64] depthwise bias, [64] conv bias (bias + w ln_b).
+// Chunk j, chunk channel cc: gate -> row (cc < 32 ? 32 j + cc : N / 2 + 32 j + cc - 32); otherwise row 64 j + cc.
+size_t pack_pw_dw_blocks(DType dt, const float* w, const float* bias, const float* ln_w, const float* ln_b, const float* wdw, const float* bdw,
+                         int N, int c, int gate, void* dst_v) {
+    const int kcs = (c / 16 + 1) / 2, nch = N / 64, pb = pw_dw_block_bytes(kcs);
+    const size_t bytes = (size_t)nch * pb;
+    if (!dst_v) return bytes;
+    char* dst = static_cast<char*>(dst_v);
+    memset(dst, 0, bytes);
+    for (int j = 0; j < nch; ++j) {
+        uint16_t* wf = reinterpret_cast<uint16_t*>(dst + (size_t)j * pb);
+        float* tail = reinterpret_cast<float*>(dst + (size_t)j * pb + (size_t)kcs * 4096);
+        auto row_of = [&](int cc) { return gate ? (cc < 32 ? 32 * j + cc : N / 2 + 32 * j + (cc - 32)) : 64 * j + cc; };
+        size_t o = 0;
         for (int kc = 0; kc < kcs; ++kc)
             for (int ct = 0; ct < 4; ++ct)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int e = 0; e < 8; ++e) {
-                        const int cc = 16 * ct + (lane & 15);
-                        const int co = cc < 32 ? 32 * j + cc : c + 32 * j + (cc - 32);
+                        const int row = row_of(16 * ct + (lane & 15));
                         const int k = 32 * kc + 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3);
-                        dst[o++] = f32_to_operand(dt, w[(size_t)co * c + k] * ln_w[k]);
+                        wf[o++] = f32_to_operand(dt, k < c ? w[(size_t)row * c + k] * ln_w[k] : 0.f);
                     }
-    for (int co = 0; co < 2 * c; ++co) {
-        double a = bias[co];
-        for (int k = 0; k < c; ++k) a += (double)w[(size_t)co * c + k] * ln_b[k];
-        bias_out[co] = (float)a;
+        for (int cc = 0; cc < 64; ++cc) {
+            const int row = row_of(cc);
+            for (int k = 0; k < 9; ++k) tail[k * 64 + cc] = wdw[(size_t)row * 9 + k];
+            tail[9 * 64 + cc] = bdw ? bdw[row] : 0.f;
+            double a = bias ? bias[row] : 0.0;
+            for (int k = 0; k < c; ++k) a += (double)w[(size_t)row * c + k] * ln_b[k];
+            tail[10 * 64 + cc] = (float)a;
+        }
     }
-    return n;
+    return bytes;
 }
 
 }  // namespace fw

@@ -89,9 +89,10 @@ struct Conv3 {
 struct RBlock {
     int c = 0, cp = 0, heads = 0, ch = 0, hid = 0, hp = 0;
     DevBuf n1w, n1b, n2w, n2b, temp, qkv, qkv_dw, proj, pin, ffn_dw, pout;
+    DevBuf front_qkv, front_ffn;   // pw_dw_fused.hip parameter blocks (c = 48 / 96): norm1 + qkv + qkv_dwconv, norm2 + project_in + dwconv
     int qkv_t = 0, proj_t = 0, pin_t = 0, pout_t = 0;
     void release() {
-        for (DevBuf* b : {&n1w, &n1b, &n2w, &n2b, &temp, &qkv, &qkv_dw, &proj, &pin, &ffn_dw, &pout}) b->release();
+        for (DevBuf* b : {&n1w, &n1b, &n2w, &n2b, &temp, &qkv, &qkv_dw, &proj, &pin, &ffn_dw, &pout, &front_qkv, &front_ffn}) b->release();
     }
 };
 
@@ -129,6 +130,7 @@ struct fw_restormer {
     DevBuf red3, red2, conv_bias, ones;
     int red3_t = 0, red2_t = 0;
     bool built = false;
+    bool fuse_front = true;   // LayerNorm + 1x1 + depthwise 3x3 (+ GDFN gate) of the 48- / 96-channel blocks as one kernel (FW_REST_FUSE_FRONT=0: A/B)
     DevBuf ws;
 };
 
@@ -201,11 +203,22 @@ void forward(fw_restormer* n, Arena& A, const uint8_t* d_in, int H, int W, uint8
         const int c = b.c, cp = b.cp, hp = b.hp, heads = b.heads, ch = b.ch;
         const size_t mark = A.top;
         void* t = typ((size_t)M * cp);
-        RUN(fw_layernorm_nhwc(dt, x, cp, M, c, (const float*)b.n1w.p, (const float*)b.n1b.p, 1e-5f, t, cp, cp, st));
-        void* qkv = typ((size_t)M * 3 * cp);
-        RUN(fw_pointwise_nhwc(dt, t, 0, cp, M, cp, b.qkv.p, nullptr, b.qkv_t, qkv, 3 * cp, nullptr, 0, nullptr, nullptr, st));
         void* qkv2 = typ((size_t)M * 3 * cp);
-        RUN(fw_dwconv3x3_nhwc(dt, qkv, 3 * cp, h, w, 3 * cp, (const float*)b.qkv_dw.p, 0, qkv2, 3 * cp, st));
+        // norm -> 1x1 -> depthwise 3x3 of the 48- / 96-channel blocks: one kernel, the 3c / 5.3c-channel tensor stays in LDS
+        auto front = [&](const DevBuf& blocks, int n_out, int mode, void* out, long ldo) {
+            PwDwParams f{};
+            f.x = x; f.ldx = cp; f.H = h; f.W = w; f.cin = c; f.ln_eps = 1e-5f; f.blocks = blocks.p; f.n_chunks = n_out / 64; f.mode = mode;
+            f.out = out; f.ldo = ldo;
+            if (run) launch_pw_dw(n->dt, f, st_);
+        };
+        if (b.front_qkv.p) {
+            front(b.front_qkv, 3 * cp, PWDW_NONE, qkv2, 3 * cp);
+        } else {
+            RUN(fw_layernorm_nhwc(dt, x, cp, M, c, (const float*)b.n1w.p, (const float*)b.n1b.p, 1e-5f, t, cp, cp, st));
+            void* qkv = typ((size_t)M * 3 * cp);
+            RUN(fw_pointwise_nhwc(dt, t, 0, cp, M, cp, b.qkv.p, nullptr, b.qkv_t, qkv, 3 * cp, nullptr, 0, nullptr, nullptr, st));
+            RUN(fw_dwconv3x3_nhwc(dt, qkv, 3 * cp, h, w, 3 * cp, (const float*)b.qkv_dw.p, 0, qkv2, 3 * cp, st));
+        }
         float* aws = f32(fw_attn_workspace_floats(heads, ch));
         float* attn = f32((size_t)heads * ch * ch);
         void* scratch = typ(fw_attn_qk_scratch_elems(M, heads, ch));
@@ -216,11 +229,15 @@ void forward(fw_restormer* n, Arena& A, const uint8_t* d_in, int H, int W, uint8
         RUN(fw_pointwise_nhwc(dt, (const char*)qkv2 + (size_t)2 * cp * 2, 0, 3 * cp, M, cp, apk, nullptr, cp / 32, t, cp, nullptr, 0, nullptr,
                               nullptr, st));
         RUN(fw_pointwise_nhwc(dt, t, 0, cp, M, cp, b.proj.p, nullptr, b.proj_t, nullptr, 0, x, cp, x, (const float*)n->ones.p, st));
-        RUN(fw_layernorm_nhwc(dt, x, cp, M, c, (const float*)b.n2w.p, (const float*)b.n2b.p, 1e-5f, t, cp, cp, st));
-        void* g = typ((size_t)M * 2 * hp);
-        RUN(fw_pointwise_nhwc(dt, t, 0, cp, M, cp, b.pin.p, nullptr, b.pin_t, g, 2 * hp, nullptr, 0, nullptr, nullptr, st));
         void* g2 = typ((size_t)M * hp);
-        RUN(fw_dwconv3x3_nhwc(dt, g, 2 * hp, h, w, 2 * hp, (const float*)b.ffn_dw.p, 1, g2, hp, st));
+        if (b.front_ffn.p) {
+            front(b.front_ffn, 2 * hp, PWDW_GATE_GELU, g2, hp);
+        } else {
+            RUN(fw_layernorm_nhwc(dt, x, cp, M, c, (const float*)b.n2w.p, (const float*)b.n2b.p, 1e-5f, t, cp, cp, st));
+            void* g = typ((size_t)M * 2 * hp);
+            RUN(fw_pointwise_nhwc(dt, t, 0, cp, M, cp, b.pin.p, nullptr, b.pin_t, g, 2 * hp, nullptr, 0, nullptr, nullptr, st));
+            RUN(fw_dwconv3x3_nhwc(dt, g, 2 * hp, h, w, 2 * hp, (const float*)b.ffn_dw.p, 1, g2, hp, st));
+        }
         RUN(fw_pointwise_nhwc(dt, g2, 0, hp, M, hp, b.pout.p, nullptr, b.pout_t, nullptr, 0, x, cp, x, (const float*)n->ones.p, st));
         A.top = mark;
     };
@@ -314,6 +331,7 @@ int fw_restormer_create(int device_id, int dim, const int* num_blocks, int num_r
         n->dim = dim;
         n->nref = num_refinement_blocks;
         n->ffn = ffn_expansion_factor;
+        if (const char* e = getenv("FW_REST_FUSE_FRONT")) n->fuse_front = atoi(e) != 0;
         for (int i = 0; i < 4; ++i) {
             if (num_blocks[i] < 0 || num_blocks[i] > 64 || heads[i] < 1) throw Error(FW_ERR_INVALID, "fw_restormer_create: bad block / head counts");
             n->nblk[i] = num_blocks[i];
@@ -410,6 +428,14 @@ int fw_restormer_finalize(fw_restormer* n) {
                     }
                 b.qkv_t = upload_pointwise(dt, b.qkv, wqkv.data(), 3 * cp, c, cp);
                 upload(b.qkv_dw, wdw.data(), wdw.size() * 4);
+                const bool fused = n->fuse_front && pw_dw_eligible(c, PWDW_NONE);
+                auto upload_front = [&](DevBuf& dst, const std::vector<float>& w1, const char* lnw, const char* lnb, const std::vector<float>& dw, int N,
+                                        int gate) {
+                    std::vector<char> pk(pack_pw_dw_blocks(dt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, N, c, gate, nullptr));
+                    pack_pw_dw_blocks(dt, w1.data(), nullptr, H(lnw).data(), H(lnb).data(), dw.data(), nullptr, N, c, gate, pk.data());
+                    upload(dst, pk.data(), pk.size());
+                };
+                if (fused) upload_front(b.front_qkv, wqkv, "norm1.body.weight", "norm1.body.bias", wdw, 3 * cp, 0);
                 b.proj_t = upload_pointwise(dt, b.proj, H("attn.project_out.weight").data(), c, c, cp);
                 // GDFN: x1 rows @ 0, x2 rows @ hp
                 const auto& wi = H("ffn.project_in.weight");
@@ -422,6 +448,7 @@ int fw_restormer_finalize(fw_restormer* n) {
                     }
                 b.pin_t = upload_pointwise(dt, b.pin, wi2.data(), 2 * hp, c, cp);
                 upload(b.ffn_dw, di2.data(), di2.size() * 4);
+                if (fused && hp % 32 == 0 && (2 * hp) % 64 == 0) upload_front(b.front_ffn, wi2, "norm2.body.weight", "norm2.body.bias", di2, 2 * hp, 1);
                 b.pout_t = upload_pointwise(dt, b.pout, H("ffn.project_out.weight").data(), c, hid, hp);
             }
         }
