@@ -284,6 +284,11 @@ int fw_attn_apply(int dtype, const void* qkv, long stride, long pixels, int v_of
  * fw_pack_pointwise(dtype, NULL, k_pad, k_pad, NULL) uint16), so that attn @ v runs through fw_pointwise_nhwc on the matrix
  * cores — what the engine uses; fw_attn_apply is the plain form of the same product. */
 int fw_attn_pack(int dtype, const float* attn, int heads, int ch, int k_pad, void* packed, void* stream);
+/* project_out folded into the attention (restormer.py / reference Attention.forward: project_out(attn @ v)): packed =
+ * (proj_weight [dim][dim] fp32) x blockdiag(attn) in fw_pack_pointwise's layout with cout_tiles 32-row tiles, so that
+ * project_out(attn @ v) + x is one fw_pointwise_nhwc over v with the residual epilogue. */
+int fw_attn_proj_pack(int dtype, const float* attn, const float* proj_weight, int heads, int ch, int k_pad, int cout_tiles, void* packed,
+                      void* stream);
 
 /* AESRGAN's AttentionBlock (reference src/framewright/processors/aesrgan_face.py:142-168, the in-tree net behind
  * AESRGANFaceRestorer): attention = softmax(q^T k) over ALL pixels, out = gamma * (v @ attention^T) + x.

@@ -36,7 +36,7 @@ EXPORTS = [
     "fw_restormer_workspace_bytes", "fw_restormer_destroy", "fw_preserve_edges_scratch_bytes", "fw_preserve_edges_u8",
     "fw_u8_to_nhwc", "fw_pixel_shuffle_add_u8",
     "fw_layernorm_nhwc", "fw_pack_pointwise", "fw_pointwise_nhwc", "fw_dwconv3x3_nhwc", "fw_attn_workspace_floats",
-    "fw_attn_matrix", "fw_attn_apply", "fw_attn_pack", "fw_pixel_shuffle2_f32", "fw_copy_channels_f32", "fw_f32_to_planar", "fw_tap_post_u8",
+    "fw_attn_matrix", "fw_attn_apply", "fw_attn_pack", "fw_attn_proj_pack", "fw_pixel_shuffle2_f32", "fw_copy_channels_f32", "fw_f32_to_planar", "fw_tap_post_u8",
     "fw_flow_accumulate_u8", "fw_flow_accumulate_finish_u8", "fw_resize_lanczos4_u8", "fw_grain_addback_u8", "fw_attn_softmax_rows", "fw_pack_pointwise_transposed", "fw_attn_qk_scratch_elems", "fw_attn_matrix_mfma",
 ]
 
@@ -200,6 +200,8 @@ def _declare_ifnet(lib: C.CDLL) -> None:
     lib.fw_attn_apply.argtypes = [i32, vp, i64, i64, i32, i32, i32, vp, vp, i64, i32, vp]
     lib.fw_attn_pack.restype = i32
     lib.fw_attn_pack.argtypes = [i32, vp, i32, i32, i32, vp, vp]
+    lib.fw_attn_proj_pack.restype = i32
+    lib.fw_attn_proj_pack.argtypes = [i32, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.fw_pixel_shuffle2_f32.restype = i32
     lib.fw_pixel_shuffle2_f32.argtypes = [vp, i64, i32, i32, i32, vp, i64, i32, i32, vp]
     lib.fw_copy_channels_f32.restype = i32

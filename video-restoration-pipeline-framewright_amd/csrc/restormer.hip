@@ -89,10 +89,11 @@ struct Conv3 {
 struct RBlock {
     int c = 0, cp = 0, heads = 0, ch = 0, hid = 0, hp = 0;
     DevBuf n1w, n1b, n2w, n2b, temp, qkv, qkv_dw, proj, pin, ffn_dw, pout;
+    DevBuf proj_f32;               // project_out fp32 [c][c]: folded into the attention matrix per forward (fw_attn_proj_pack)
     DevBuf front_qkv, front_ffn;   // pw_dw_fused.hip parameter blocks (c = 48 / 96): norm1 + qkv + qkv_dwconv, norm2 + project_in + dwconv
     int qkv_t = 0, proj_t = 0, pin_t = 0, pout_t = 0;
     void release() {
-        for (DevBuf* b : {&n1w, &n1b, &n2w, &n2b, &temp, &qkv, &qkv_dw, &proj, &pin, &ffn_dw, &pout, &front_qkv, &front_ffn}) b->release();
+        for (DevBuf* b : {&n1w, &n1b, &n2w, &n2b, &temp, &qkv, &qkv_dw, &proj, &pin, &ffn_dw, &pout, &front_qkv, &front_ffn, &proj_f32}) b->release();
     }
 };
 
@@ -130,6 +131,7 @@ struct fw_restormer {
     DevBuf red3, red2, conv_bias, ones;
     int red3_t = 0, red2_t = 0;
     bool built = false;
+    bool merge_proj = true;   // project_out folded into the attention matrix: one GEMM pass instead of two (FW_REST_MERGE_PROJ=0: A/B)
     bool fuse_front = true;   // LayerNorm + 1x1 + depthwise 3x3 (+ GDFN gate) of the 48- / 96-channel blocks as one kernel (FW_REST_FUSE_FRONT=0: A/B)
     DevBuf ws;
 };
@@ -225,10 +227,17 @@ void forward(fw_restormer* n, Arena& A, const uint8_t* d_in, int H, int W, uint8
         RUN(fw_attn_matrix_mfma(dt, qkv2, 3 * cp, M, cp, heads, ch, (const float*)b.temp.p, aws, scratch, attn, st));
         // attn @ v as a 1x1 convolution with the block-diagonal attention matrix on the MFMA GEMM
         void* apk = typ(fw_pack_pointwise(dt, nullptr, cp, cp, nullptr));
-        RUN(fw_attn_pack(dt, attn, heads, ch, cp, apk, st));
-        RUN(fw_pointwise_nhwc(dt, (const char*)qkv2 + (size_t)2 * cp * 2, 0, 3 * cp, M, cp, apk, nullptr, cp / 32, t, cp, nullptr, 0, nullptr,
-                              nullptr, st));
-        RUN(fw_pointwise_nhwc(dt, t, 0, cp, M, cp, b.proj.p, nullptr, b.proj_t, nullptr, 0, x, cp, x, (const float*)n->ones.p, st));
+        if (n->merge_proj) {
+            // x += (project_out . attn) v: the two matrices are multiplied first (c x c x ch MACs), the pixels see one GEMM
+            RUN(fw_attn_proj_pack(dt, attn, (const float*)b.proj_f32.p, heads, ch, cp, b.proj_t, apk, st));
+            RUN(fw_pointwise_nhwc(dt, (const char*)qkv2 + (size_t)2 * cp * 2, 0, 3 * cp, M, cp, apk, nullptr, b.proj_t, nullptr, 0, x, cp, x,
+                                  (const float*)n->ones.p, st));
+        } else {
+            RUN(fw_attn_pack(dt, attn, heads, ch, cp, apk, st));
+            RUN(fw_pointwise_nhwc(dt, (const char*)qkv2 + (size_t)2 * cp * 2, 0, 3 * cp, M, cp, apk, nullptr, cp / 32, t, cp, nullptr, 0, nullptr,
+                                  nullptr, st));
+            RUN(fw_pointwise_nhwc(dt, t, 0, cp, M, cp, b.proj.p, nullptr, b.proj_t, nullptr, 0, x, cp, x, (const float*)n->ones.p, st));
+        }
         void* g2 = typ((size_t)M * hp);
         if (b.front_ffn.p) {
             front(b.front_ffn, 2 * hp, PWDW_GATE_GELU, g2, hp);
@@ -332,6 +341,7 @@ int fw_restormer_create(int device_id, int dim, const int* num_blocks, int num_r
         n->nref = num_refinement_blocks;
         n->ffn = ffn_expansion_factor;
         if (const char* e = getenv("FW_REST_FUSE_FRONT")) n->fuse_front = atoi(e) != 0;
+        if (const char* e = getenv("FW_REST_MERGE_PROJ")) n->merge_proj = atoi(e) != 0;
         for (int i = 0; i < 4; ++i) {
             if (num_blocks[i] < 0 || num_blocks[i] > 64 || heads[i] < 1) throw Error(FW_ERR_INVALID, "fw_restormer_create: bad block / head counts");
             n->nblk[i] = num_blocks[i];
@@ -437,6 +447,7 @@ int fw_restormer_finalize(fw_restormer* n) {
                 };
                 if (fused) upload_front(b.front_qkv, wqkv, "norm1.body.weight", "norm1.body.bias", wdw, 3 * cp, 0);
                 b.proj_t = upload_pointwise(dt, b.proj, H("attn.project_out.weight").data(), c, c, cp);
+                upload(b.proj_f32, H("attn.project_out.weight").data(), (size_t)c * c * 4);
                 // GDFN: x1 rows @ 0, x2 rows @ hp
                 const auto& wi = H("ffn.project_in.weight");
                 const auto& di = H("ffn.dwconv.weight");

@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void attn_reduce_kernel(float* partial, int nb
 
 // A[h][c1][:] = softmax_c2(G / (|q_c1| |k_c2|) * temperature[h]) with F.normalize's clamp (norm >= 1e-12), from the reduced
 // sums.  One workgroup per (head, c1) row.
-__global__ __launch_bounds__(128) void attn_finish_kernel(const float* __restrict__ sums, int heads, int ch,
+__global__ __launch_bounds__(128) void attn_finish_kernel(const float* __restrict__ sums, int rows, long stride, int heads, int ch,
                                                           const float* __restrict__ temperature, float* attn) {
     __shared__ float row[128];
     __shared__ float red[128];
@@ -487,9 +487,14 @@ __global__ __launch_bounds__(128) void attn_finish_kernel(const float* __restric
     const int h = blockIdx.x / ch, c1 = blockIdx.x - h * ch;
     const int c2 = threadIdx.x;
     if (c2 < ch) {
-        const float g = sums[(h * ch + c1) * ch + c2];
-        const float kn = sums[dim * ch + dim + h * ch + c2];
-        const float qn = sums[dim * ch + h * ch + c1];
+        // the last level of the reduction happens here: rows 0 .. rows-1 of the workspace, in order (deterministic)
+        float g = 0.f, kn = 0.f, qn = 0.f;
+        for (int b = 0; b < rows; ++b) {
+            const float* sb = sums + (size_t)b * stride;
+            g += sb[(h * ch + c1) * ch + c2];
+            kn += sb[dim * ch + dim + h * ch + c2];
+            qn += sb[dim * ch + h * ch + c1];
+        }
         const float dq = fmaxf(sqrtf(qn), 1e-12f), dk = fmaxf(sqrtf(kn), 1e-12f);
         row[c2] = g / (dq * dk) * temperature[h];
     }
@@ -529,6 +534,32 @@ __global__ __launch_bounds__(256) void attn_pack_kernel(const float* __restrict_
         const int co = 32 * t + (lane & 31), k = 32 * c + 16 * ks + 8 * (lane >> 5) + j;
         float v = 0.f;
         if (co < dim && k < dim && co / ch == k / ch) v = attn[((size_t)(co / ch) * ch + co % ch) * ch + k % ch];
+        dst[i] = (T)v;
+    }
+}
+
+// project_out folded into the attention: y = Wp (A v) = (Wp A) v.  Wc[co][h ch + c2] = sum_c1 Wp[co][h ch + c1] A[h][c1][c2] in the
+// fragment order of pack_pointwise_weights (kp x 32 nt), so that "project_out(attn @ v) + x" is ONE 1x1 convolution on v with a
+// residual epilogue (before: two GEMM passes over the pixels and a typed tensor between them).
+template <typename T>
+__global__ __launch_bounds__(256) void attn_proj_pack_kernel(const float* __restrict__ attn, const float* __restrict__ wp, int heads, int ch,
+                                                             int kp, int nt, T* dst) {
+    const int dim = heads * ch;
+    const long total = (long)(kp / 32) * 2 * nt * 64 * 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        long r = i >> 9;
+        const int t = (int)(r % nt);
+        r /= nt;
+        const int ks = (int)(r & 1), c = (int)(r >> 1);
+        const int co = 32 * t + (lane & 31), k = 32 * c + 16 * ks + 8 * (lane >> 5) + j;
+        float v = 0.f;
+        if (co < dim && k < dim) {
+            const int h = k / ch, c2 = k - h * ch;
+            const float* w = wp + (size_t)co * dim + h * ch;
+            const float* a = attn + (size_t)h * ch * ch + c2;
+            for (int c1 = 0; c1 < ch; ++c1) v += w[c1] * a[(size_t)c1 * ch];
+        }
         dst[i] = (T)v;
     }
 }
@@ -811,8 +842,7 @@ int fw_attn_matrix(int dtype, const void* qkv, long ld, long M, int k_off, int h
         const int G = nb < 32 ? 1 : 32;
         if (G > 1)
             hipLaunchKernelGGL(attn_reduce_kernel, dim3((unsigned)((stride + 255) / 256), G), dim3(256), 0, st, workspace, nb, stride, G);
-        hipLaunchKernelGGL(attn_reduce_kernel, dim3((unsigned)((stride + 255) / 256), 1), dim3(256), 0, st, workspace, G > 1 ? G : nb, stride, 1);
-        hipLaunchKernelGGL(attn_finish_kernel, dim3(heads * ch), dim3(128), 0, st, (const float*)workspace, heads, ch, temperature, attn);
+        hipLaunchKernelGGL(attn_finish_kernel, dim3(heads * ch), dim3(128), 0, st, (const float*)workspace, G > 1 ? G : nb, stride, heads, ch, temperature, attn);
         FW_HIP_CHECK(hipGetLastError());
     });
 }
@@ -852,8 +882,7 @@ int fw_attn_matrix_mfma(int dtype, const void* qkv, long ld, long M, int k_off, 
         const int G = nb < 32 ? 1 : 32;
         if (G > 1)
             hipLaunchKernelGGL(attn_reduce_kernel, dim3((unsigned)((stride + 255) / 256), G), dim3(256), 0, st, workspace, nb, stride, G);
-        hipLaunchKernelGGL(attn_reduce_kernel, dim3((unsigned)((stride + 255) / 256), 1), dim3(256), 0, st, workspace, G > 1 ? G : nb, stride, 1);
-        hipLaunchKernelGGL(attn_finish_kernel, dim3(heads * ch), dim3(128), 0, st, (const float*)workspace, heads, ch, temperature, attn);
+        hipLaunchKernelGGL(attn_finish_kernel, dim3(heads * ch), dim3(128), 0, st, (const float*)workspace, G > 1 ? G : nb, stride, heads, ch, temperature, attn);
         FW_HIP_CHECK(hipGetLastError());
     });
 }
@@ -868,6 +897,24 @@ int fw_attn_pack(int dtype, const float* attn, int heads, int ch, int k_pad, voi
             hipLaunchKernelGGL((attn_pack_kernel<__bf16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, attn, heads, ch, k_pad, (__bf16*)packed);
         else
             hipLaunchKernelGGL((attn_pack_kernel<_Float16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, attn, heads, ch, k_pad, (_Float16*)packed);
+        FW_HIP_CHECK(hipGetLastError());
+    });
+}
+
+int fw_attn_proj_pack(int dtype, const float* attn, const float* proj_weight, int heads, int ch, int k_pad, int cout_tiles, void* packed,
+                      void* stream) {
+    if (bad_dtype(dtype) || !attn || !proj_weight || !packed || heads < 1 || ch < 8 || k_pad < heads * ch || (k_pad & 31) || cout_tiles < 1 ||
+        32 * cout_tiles < heads * ch)
+        return rfail(FW_ERR_INVALID, "fw_attn_proj_pack: bad argument");
+    return rguard([&] {
+        const long total = (long)(k_pad / 32) * 2 * cout_tiles * 64 * 8;
+        const int blocks = blocks_for(total, 1024);
+        if (dtype == FW_DTYPE_BF16)
+            hipLaunchKernelGGL((attn_proj_pack_kernel<__bf16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, attn, proj_weight, heads, ch, k_pad,
+                               cout_tiles, (__bf16*)packed);
+        else
+            hipLaunchKernelGGL((attn_proj_pack_kernel<_Float16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, attn, proj_weight, heads, ch, k_pad,
+                               cout_tiles, (_Float16*)packed);
         FW_HIP_CHECK(hipGetLastError());
     });
 }
