@@ -302,7 +302,33 @@ __global__ __launch_bounds__(512, 2) void pw_dw_kernel(const PwDwParams p) {
             __syncthreads();
             FW_PH(6);
 #ifndef FW_FRONT_ABL_STORE   // timing only: no stores (the sums keep the arithmetic alive)
-            {
+            bool transposed = false;
+            if constexpr (MODE == PWDW_NONE) transposed = p.qT && j < 2 * p.t_chunks;
+            if (transposed) {
+                // q / k for the Gram kernel: 16 bytes = 8 pixels of one channel, pixels in tile order, zeros where the tile has none
+                const bool is_k = j >= p.t_chunks;
+                T* dst = reinterpret_cast<T*>(is_k ? p.kT : p.qT) + 64 * 8 * (is_k ? j - p.t_chunks : j);
+                constexpr int GROUPS = (FR_OR * FR_OC + 7) / 8 + 3;   // 56: 448 pixels, a multiple of 32
+                // a wave handles one pixel group per round (lane = channel): which pixels, and whether they exist, is scalar work
+                const char* ych = ybuf + FR_PXB * (FR_HC + 1) + 2 * lane;
+#pragma unroll 1
+                for (int gq = wave; gq < GROUPS; gq += 8) {
+                    unsigned w4[4];
+                    int orow = (gq * 8) / FR_OC, ocol = gq * 8 - orow * FR_OC;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const bool ok = gq * 8 + e < FR_OR * FR_OC && ty0 + orow < p.H && tx0 + ocol < p.W;     // wave-uniform
+                        unsigned u = 0;
+                        if (ok) u = *reinterpret_cast<const unsigned short*>(ych + (orow * FR_HC + ocol) * FR_PXB);
+                        if (e & 1) w4[e >> 1] |= u << 16; else w4[e >> 1] = u;
+                        if (++ocol == FR_OC) {
+                            ocol = 0;
+                            ++orow;
+                        }
+                    }
+                    store16(dst + (((long)tile * GROUPS + gq) * p.t_ld + lane) * 8, make_uint4(w4[0], w4[1], w4[2], w4[3]));
+                }
+            } else {
                 constexpr int PPX = OUT_B / 16;               // 16-byte pieces per pixel
                 T* obase = reinterpret_cast<T*>(p.out) + (OUT_B / 2) * j;
 #pragma unroll
@@ -360,6 +386,10 @@ static int front_cus() {
     return n;
 }
 
+long pw_dw_transposed_pixels(int H, int W) {
+    return (long)((H + FR_OR - 1) / FR_OR) * ((W + FR_OC - 1) / FR_OC) * 448;
+}
+
 int pw_dw_blocks(int H, int W) {
     const long tiles = (long)((H + FR_OR - 1) / FR_OR) * ((W + FR_OC - 1) / FR_OC);
     return (int)(tiles < front_cus() ? tiles : front_cus());
@@ -373,7 +403,8 @@ bool pw_dw_eligible(int cin, int mode) {
 
 void launch_pw_dw(DType dt, const PwDwParams& p, hipStream_t st) {
     if (!pw_dw_eligible(p.cin, p.mode) || p.H <= 0 || p.W <= 0 || (p.ldx % 4) || (p.ldo % 8) || !p.x || !p.blocks || !p.out || p.n_chunks < 1 ||
-        (p.mode == PWDW_GATE_MUL && p.n_chunks > 4))
+        (p.mode == PWDW_GATE_MUL && p.n_chunks > 4) || ((p.qT || p.kT) && (!p.qT || !p.kT || p.mode != PWDW_NONE || p.t_chunks < 1 ||
+                                                        3 * p.t_chunks != p.n_chunks || p.t_ld < 64 * p.t_chunks)))
         throw Error(1, "pw_dw: shape not eligible");
     dim3 grid((unsigned)pw_dw_blocks(p.H, p.W)), block(512);
 #define FW_F(CG, MODE)                                                                            \

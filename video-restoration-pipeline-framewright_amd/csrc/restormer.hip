@@ -131,6 +131,7 @@ struct fw_restormer {
     DevBuf red3, red2, conv_bias, ones;
     int red3_t = 0, red2_t = 0;
     bool built = false;
+    bool qk_direct = true;    // the fused qkv front writes q / k in the Gram kernel's operand layout (FW_REST_QK_DIRECT=0: pixel-major + transpose pass)
     bool merge_proj = true;   // project_out folded into the attention matrix: one GEMM pass instead of two (FW_REST_MERGE_PROJ=0: A/B)
     bool fuse_front = true;   // LayerNorm + 1x1 + depthwise 3x3 (+ GDFN gate) of the 48- / 96-channel blocks as one kernel (FW_REST_FUSE_FRONT=0: A/B)
     DevBuf ws;
@@ -213,18 +214,31 @@ void forward(fw_restormer* n, Arena& A, const uint8_t* d_in, int H, int W, uint8
             f.out = out; f.ldo = ldo;
             if (run) launch_pw_dw(n->dt, f, st_);
         };
+        float* attn = f32((size_t)heads * ch * ch);
+        float* aws = f32(fw_attn_workspace_floats(heads, ch));
         if (b.front_qkv.p) {
-            front(b.front_qkv, 3 * cp, PWDW_NONE, qkv2, 3 * cp);
+            // q and k leave the kernel already in the Gram kernel's operand layout (no pixel-major copy of them, no transpose pass)
+            const long Mp = pw_dw_transposed_pixels(h, w);
+            void* qT = n->qk_direct ? typ((size_t)Mp * cp) : nullptr;
+            void* kT = n->qk_direct ? typ((size_t)Mp * cp) : nullptr;
+            PwDwParams f{};
+            f.x = x; f.ldx = cp; f.H = h; f.W = w; f.cin = c; f.ln_eps = 1e-5f; f.blocks = b.front_qkv.p; f.n_chunks = 3 * cp / 64; f.mode = PWDW_NONE;
+            f.out = qkv2; f.ldo = 3 * cp; f.qT = qT; f.kT = kT; f.t_chunks = cp / 64; f.t_ld = cp;
+            if (run) launch_pw_dw(n->dt, f, st_);
+            if (n->qk_direct) {
+                if (run) launch_attn_matrix_from_transposed(n->dt, qT, kT, Mp, cp, heads, ch, (const float*)b.temp.p, aws, attn, st_);
+            } else {
+                void* scratch = typ(fw_attn_qk_scratch_elems(M, heads, ch));
+                RUN(fw_attn_matrix_mfma(dt, qkv2, 3 * cp, M, cp, heads, ch, (const float*)b.temp.p, aws, scratch, attn, st));
+            }
         } else {
             RUN(fw_layernorm_nhwc(dt, x, cp, M, c, (const float*)b.n1w.p, (const float*)b.n1b.p, 1e-5f, t, cp, cp, st));
             void* qkv = typ((size_t)M * 3 * cp);
             RUN(fw_pointwise_nhwc(dt, t, 0, cp, M, cp, b.qkv.p, nullptr, b.qkv_t, qkv, 3 * cp, nullptr, 0, nullptr, nullptr, st));
             RUN(fw_dwconv3x3_nhwc(dt, qkv, 3 * cp, h, w, 3 * cp, (const float*)b.qkv_dw.p, 0, qkv2, 3 * cp, st));
+            void* scratch = typ(fw_attn_qk_scratch_elems(M, heads, ch));
+            RUN(fw_attn_matrix_mfma(dt, qkv2, 3 * cp, M, cp, heads, ch, (const float*)b.temp.p, aws, scratch, attn, st));
         }
-        float* aws = f32(fw_attn_workspace_floats(heads, ch));
-        float* attn = f32((size_t)heads * ch * ch);
-        void* scratch = typ(fw_attn_qk_scratch_elems(M, heads, ch));
-        RUN(fw_attn_matrix_mfma(dt, qkv2, 3 * cp, M, cp, heads, ch, (const float*)b.temp.p, aws, scratch, attn, st));
         // attn @ v as a 1x1 convolution with the block-diagonal attention matrix on the MFMA GEMM
         void* apk = typ(fw_pack_pointwise(dt, nullptr, cp, cp, nullptr));
         if (n->merge_proj) {
@@ -342,6 +356,7 @@ int fw_restormer_create(int device_id, int dim, const int* num_blocks, int num_r
         n->ffn = ffn_expansion_factor;
         if (const char* e = getenv("FW_REST_FUSE_FRONT")) n->fuse_front = atoi(e) != 0;
         if (const char* e = getenv("FW_REST_MERGE_PROJ")) n->merge_proj = atoi(e) != 0;
+        if (const char* e = getenv("FW_REST_QK_DIRECT")) n->qk_direct = atoi(e) != 0;
         for (int i = 0; i < 4; ++i) {
             if (num_blocks[i] < 0 || num_blocks[i] > 64 || heads[i] < 1) throw Error(FW_ERR_INVALID, "fw_restormer_create: bad block / head counts");
             n->nblk[i] = num_blocks[i];

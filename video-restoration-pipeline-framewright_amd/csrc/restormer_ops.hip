@@ -383,7 +383,7 @@ __device__ __forceinline__ gram_f4 gram_mfma<_Float16>(uint4 a, uint4 b, gram_f4
 // the layout attn_reduce_kernel / attn_finish_kernel read).
 template <typename T, int NT>
 __global__ __launch_bounds__(256) void attn_gram_mfma_kernel(const T* __restrict__ qT, const T* __restrict__ kT, long Mp, int heads,
-                                                             float* partial) {
+                                                             int ldc /* channels per pixel group in qT / kT (>= heads * ch) */, float* partial) {
     constexpr int ch = 16 * NT;
     __shared__ float red[NT * NT * 256 + 2 * NT * 16];
     const int h = blockIdx.y, dim = heads * ch;
@@ -404,8 +404,8 @@ __global__ __launch_bounds__(256) void attn_gram_mfma_kernel(const T* __restrict
         uint4 a[NT], b[NT];
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
-            a[i] = *reinterpret_cast<const uint4*>(qT + (pg * dim + h * ch + 16 * i + r) * 8);
-            b[i] = *reinterpret_cast<const uint4*>(kT + (pg * dim + h * ch + 16 * i + r) * 8);
+            a[i] = *reinterpret_cast<const uint4*>(qT + (pg * ldc + h * ch + 16 * i + r) * 8);
+            b[i] = *reinterpret_cast<const uint4*>(kT + (pg * ldc + h * ch + 16 * i + r) * 8);
         }
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
@@ -872,9 +872,9 @@ int fw_attn_matrix_mfma(int dtype, const void* qkv, long ld, long M, int k_off, 
         T* kT = qT + half;                                                                                                    \
         hipLaunchKernelGGL((qk_transpose_kernel<T>), dim3(tb), dim3(256), 0, st, (const T*)qkv, ld, M, Mp, k_off, dim, qT, kT); \
         if (ch == 48)                                                                                                         \
-            hipLaunchKernelGGL((attn_gram_mfma_kernel<T, 3>), dim3(nb, heads), dim3(256), 0, st, (const T*)qT, (const T*)kT, Mp, heads, workspace); \
+            hipLaunchKernelGGL((attn_gram_mfma_kernel<T, 3>), dim3(nb, heads), dim3(256), 0, st, (const T*)qT, (const T*)kT, Mp, heads, dim, workspace); \
         else                                                                                                                  \
-            hipLaunchKernelGGL((attn_gram_mfma_kernel<T, 6>), dim3(nb, heads), dim3(256), 0, st, (const T*)qT, (const T*)kT, Mp, heads, workspace); \
+            hipLaunchKernelGGL((attn_gram_mfma_kernel<T, 6>), dim3(nb, heads), dim3(256), 0, st, (const T*)qT, (const T*)kT, Mp, heads, dim, workspace); \
     } while (0)
         if (dtype == FW_DTYPE_BF16) FW_GM(__bf16); else FW_GM(_Float16);
 #undef FW_GM
@@ -886,6 +886,37 @@ int fw_attn_matrix_mfma(int dtype, const void* qkv, long ld, long M, int k_off, 
         FW_HIP_CHECK(hipGetLastError());
     });
 }
+
+// The attention matrices from q and k already held as [pixel group of 8][ldc channels][8 pixels] (pw_dw_fused.hip writes them that
+// way, in its own pixel order and zero padded per tile - the Gram sum does not care about the order): Gram partials, reduction,
+// softmax.  Mp: pixels including padding, a multiple of 32.
+}  // extern "C"
+namespace fw {
+void launch_attn_matrix_from_transposed(DType dt, const void* qT, const void* kT, long Mp, int ldc, int heads, int ch, const float* temperature,
+                                        float* workspace, float* attn, hipStream_t st) {
+    const int dim = heads * ch;
+    if (!qT || !kT || !temperature || !workspace || !attn || Mp < 32 || (Mp & 31) || heads < 1 || (ch != 48 && ch != 96) || dim > 512 || ldc < dim)
+        throw Error(FW_ERR_INVALID, "attn_matrix_from_transposed: bad argument");
+    const long steps = Mp / 32;
+    const long nbl = steps / 8;
+    const int nb = (int)(nbl < 1 ? 1 : (nbl > GRAM_MAX_BLOCKS ? GRAM_MAX_BLOCKS : nbl));
+#define FW_GM(T)                                                                                                                        \
+    do {                                                                                                                                \
+        if (ch == 48)                                                                                                                   \
+            hipLaunchKernelGGL((attn_gram_mfma_kernel<T, 3>), dim3(nb, heads), dim3(256), 0, st, (const T*)qT, (const T*)kT, Mp, heads, ldc, workspace); \
+        else                                                                                                                            \
+            hipLaunchKernelGGL((attn_gram_mfma_kernel<T, 6>), dim3(nb, heads), dim3(256), 0, st, (const T*)qT, (const T*)kT, Mp, heads, ldc, workspace); \
+    } while (0)
+    if (dt == DT_BF16) FW_GM(__bf16); else FW_GM(_Float16);
+#undef FW_GM
+    const long stride = (long)dim * ch + 2 * dim;
+    const int G = nb < 32 ? 1 : 32;
+    if (G > 1) hipLaunchKernelGGL(attn_reduce_kernel, dim3((unsigned)((stride + 255) / 256), G), dim3(256), 0, st, workspace, nb, stride, G);
+    hipLaunchKernelGGL(attn_finish_kernel, dim3(heads * ch), dim3(128), 0, st, (const float*)workspace, G > 1 ? G : nb, stride, heads, ch, temperature, attn);
+    FW_HIP_CHECK(hipGetLastError());
+}
+}  // namespace fw
+extern "C" {
 
 int fw_attn_pack(int dtype, const float* attn, int heads, int ch, int k_pad, void* packed, void* stream) {
     if (bad_dtype(dtype) || !attn || !packed || heads < 1 || ch < 8 || k_pad < heads * ch || (k_pad & 31))
