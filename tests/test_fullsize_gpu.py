@@ -109,7 +109,47 @@ def test_tap_1080p_reference_tiling_tile_vs_oracle_and_bit_exact_blend(hip_lib):
     dn.clear_cache()
 
 
-def test_chain_1080p_equals_stage_by_stage(hip_lib):
+def test_nafnet_1080p_hipgraph_replay_equals_direct_launches(hip_lib, monkeypatch):
+    """BASELINE configs[4] names hipGraph-captured per-frame stages: the NAFNet forward captured once (FW_NAF_GRAPH=1) and replayed
+    produces the frame the direct launches produce, also after the weights were replaced (captures are dropped with them)."""
+    sd = synthetic_nafnet_state(**T.NAFNET_ARGS)
+    f = torch.from_numpy(synthetic_frames(1, H, W, seed=6)[0]).cuda()
+    eng = T.NAFNetEngine(dtype="f16", **T.NAFNET_ARGS)
+    eng.load_state_dict(sd)
+    want = torch.empty_like(f)
+    eng.denoise_device(f, out=want)
+    torch.cuda.synchronize()
+    eng.close()
+    monkeypatch.setenv("FW_NAF_GRAPH", "1")
+    g = T.NAFNetEngine(dtype="f16", **T.NAFNET_ARGS)
+    g.load_state_dict(sd)
+    out = torch.empty_like(f)
+    for _ in range(3):                                                          # first call direct, second captures, third replays
+        out.zero_()
+        g.denoise_device(f, out=out)
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    sd2 = synthetic_nafnet_state(seed=9, **T.NAFNET_ARGS)
+    g.load_state_dict(sd2)                                                      # new weights: the captured graph must not be replayed
+    g.denoise_device(f, out=out)
+    g.denoise_device(f, out=out)
+    torch.cuda.synchronize()
+    g.close()
+    monkeypatch.delenv("FW_NAF_GRAPH")
+    e2 = T.NAFNetEngine(dtype="f16", **T.NAFNET_ARGS)
+    e2.load_state_dict(sd2)
+    want2 = torch.empty_like(f)
+    e2.denoise_device(f, out=want2)
+    torch.cuda.synchronize()
+    assert torch.equal(out, want2) and not torch.equal(want2, want)
+    e2.close()
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_chain_1080p_equals_stage_by_stage(hip_lib, monkeypatch, graphs):
+    if graphs:   # every stage replays (or re-captures, where the pipeline hands over fresh buffers) a hipGraph of its forward
+        for k in ("FW_NAF_GRAPH", "FW_RRDB_GRAPH", "FW_IFNET_GRAPH"):
+            monkeypatch.setenv(k, "1")
     frames = list(synthetic_frames(4, H, W, seed=5))
     naf = T.NAFNetEngine(dtype="f16", **T.NAFNET_ARGS)
     naf.load_state_dict(synthetic_nafnet_state(**T.NAFNET_ARGS))

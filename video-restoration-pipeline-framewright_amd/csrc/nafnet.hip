@@ -69,6 +69,18 @@ struct fw_nafnet {
     bool gemm = true;      // 1x1 convs of the levels with >= 256 channels on pointwise_gemm.hip (FW_NAF_GEMM=0: A/B)
     bool fuse_tail = true; // conv3 .. conv5 of a width-64 block as one kernel (FW_NAF_FUSE_TAIL=0: A/B)
     bool fuse_front = true; // norm1 + conv1 + depthwise conv + gate of a 64- / 128-channel block as one kernel (FW_NAF_FUSE_FRONT=0)
+    // hipGraph replay of a forward (BASELINE configs[4]: "hipGraph-captured per-frame stages"), keyed by everything a captured launch
+    // sequence bakes in (FW_NAF_GRAPH=1; off by default: a caller that hands over fresh buffers every frame would re-capture every frame)
+    int graph_mode = 0;
+    bool warmed = false;
+    struct GraphEntry {
+        int H, W;
+        const void* in;
+        void *out, *rgb;
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+    };
+    std::vector<GraphEntry> graphs;
 };
 
 namespace {
@@ -99,6 +111,14 @@ struct DevGuard {
     }
     ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
+
+void drop_graphs(fw_nafnet* n) {
+    for (auto& g : n->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    n->graphs.clear();
+}
 
 void upload(DevBuf& b, const void* src, size_t bytes) {
     b.release();
@@ -371,6 +391,7 @@ int fw_nafnet_create(int device_id, int width, int middle_blk_num, const int* en
         if (const char* e = getenv("FW_NAF_GEMM")) n->gemm = atoi(e) != 0;
         if (const char* e = getenv("FW_NAF_FUSE_TAIL")) n->fuse_tail = atoi(e) != 0;
         if (const char* e = getenv("FW_NAF_FUSE_FRONT")) n->fuse_front = atoi(e) != 0;
+        if (const char* e = getenv("FW_NAF_GRAPH")) n->graph_mode = atoi(e);
         n->device = device_id;
         n->dt = (DType)dtype;
         n->width = width;
@@ -402,6 +423,10 @@ int fw_nafnet_set_tensor(fw_nafnet* n, const char* key_c, const float* data, siz
     return guarded([&] {
         std::lock_guard<std::mutex> lk(n->mu);
         DevGuard dg(n->device);
+        if (!n->graphs.empty()) {   // captured forwards hold the addresses of the weights being replaced
+            FW_HIP_CHECK(hipDeviceSynchronize());
+            drop_graphs(n);
+        }
         const std::string key(key_c);
         const int w = n->width;
         if (key == "intro.weight") { need(numel, (size_t)w * 3 * 9, key); upload_conv3(n->dt, n->intro_w, data, w, 3); n->have_intro_w = true; return; }
@@ -496,6 +521,7 @@ int fw_nafnet_denoise_u8(fw_nafnet* n, const uint8_t* in_bgr, int in_loc, int H,
         const Plan pl = make_plan(n, H, W);
         if (n->ws.bytes < pl.total) {
             FW_HIP_CHECK(hipDeviceSynchronize());
+            drop_graphs(n);
             n->ws.release();
             FW_HIP_CHECK(hipMalloc(&n->ws.p, pl.total));
             n->ws.bytes = pl.total;
@@ -509,7 +535,44 @@ int fw_nafnet_denoise_u8(fw_nafnet* n, const uint8_t* in_bgr, int in_loc, int H,
         }
         uint8_t* d_out = out_bgr;
         if (out_bgr && out_loc == FW_HOST) d_out = (uint8_t*)n->ws.p + pl.out_u8;
-        forward(n, d_in, H, W, d_out, out_rgb_f32, st);
+        const bool graphed = n->warmed && n->graph_mode == 1;   // the first forward runs eagerly: lazy one-time set-up stays out of a capture
+        n->warmed = true;
+        if (!graphed) {
+            forward(n, d_in, H, W, d_out, out_rgb_f32, st);
+        } else {
+            fw_nafnet::GraphEntry* hit = nullptr;
+            for (auto& g : n->graphs)
+                if (g.H == H && g.W == W && g.in == d_in && g.out == d_out && g.rgb == out_rgb_f32) hit = &g;
+            if (!hit) {
+                if (n->graphs.size() >= 16) drop_graphs(n);
+                (void)conv_zero_page();   // its first use allocates: not inside a capture
+                hipStream_t cs = nullptr;
+                FW_HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+                fw_nafnet::GraphEntry e{H, W, d_in, d_out, out_rgb_f32, nullptr, nullptr};
+                hipError_t err = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+                if (err == hipSuccess) {
+                    try {
+                        forward(n, d_in, H, W, d_out, out_rgb_f32, cs);
+                    } catch (...) {
+                        hipGraph_t junk = nullptr;
+                        (void)hipStreamEndCapture(cs, &junk);
+                        if (junk) (void)hipGraphDestroy(junk);
+                        (void)hipStreamDestroy(cs);
+                        throw;
+                    }
+                    err = hipStreamEndCapture(cs, &e.graph);
+                }
+                if (err == hipSuccess) err = hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0);
+                (void)hipStreamDestroy(cs);
+                if (err != hipSuccess) {
+                    if (e.graph) (void)hipGraphDestroy(e.graph);
+                    FW_HIP_CHECK(err);
+                }
+                n->graphs.push_back(e);
+                hit = &n->graphs.back();
+            }
+            FW_HIP_CHECK(hipGraphLaunch(hit->exec, st));
+        }
         if (out_bgr && out_loc == FW_HOST) {
             FW_HIP_CHECK(hipMemcpyAsync(out_bgr, d_out, bytes, hipMemcpyDeviceToHost, st));
             FW_HIP_CHECK(hipStreamSynchronize(st));
@@ -598,13 +661,15 @@ int fw_resize_lanczos4_u8(const uint8_t* src, int src_h, int src_w, int channels
 
 int fw_nafnet_destroy(fw_nafnet* n) {
     if (!n) return FW_OK;
+    { std::lock_guard<std::mutex> lk(n->mu); }   // a call in flight on another thread finishes first
     int prev = -1;
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(n->device);
     (void)hipDeviceSynchronize();
+    drop_graphs(n);
     auto free_block = [](Block& b) {
         for (DevBuf* d : {&b.n1w, &b.n1b, &b.n2w, &b.n2b, &b.beta, &b.gamma, &b.w1, &b.b1, &b.w3, &b.b3, &b.w4, &b.b4, &b.w5, &b.w1g, &b.w3g, &b.w4g, &b.w5g,
-                          &b.b5, &b.wdw, &b.bdw, &b.wsca, &b.bsca})
+                          &b.b5, &b.wdw, &b.bdw, &b.wsca, &b.bsca, &b.front})
             d->release();
     };
     for (auto& v : n->encoders) for (auto& b : v) free_block(b);
