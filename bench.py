@@ -95,20 +95,24 @@ def lib_digest():
 
 def nafnet_design_bytes(H, W, width=64, enc=(2, 2, 4, 8), mid=12, dec=(2, 2, 2, 2)):
     """HBM bytes one NAFNet forward moves in THIS engine's dataflow, every tensor counted once per kernel that reads or writes
-    it: per NAFBlock at c channels 48c bytes per pixel (fp32 residual stream read twice and written
-    twice, five typed tensors), plus the 2x2 down convs, the 1x1 + PixelShuffle ups, intro and ending."""
+    it.  Per NAFBlock and pixel, c channels: 16c at c = 64 (two kernels: the fused front reads the fp32
+    stream and writes the gated tensor, the fused tail reads both and writes the stream), 36c at c = 128 (fused front, then conv3 /
+    LayerNorm / conv4 + gate / conv5 as four passes), 48c from 256 channels up (seven passes: fp32 stream read twice and written
+    twice, five typed tensors - the round-1 figure for every level); plus the 2x2 down convs, the 1x1 + PixelShuffle ups, intro
+    and ending."""
     Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
     px, c, total = Hp * Wp, width, 0.0
+    per_block = lambda ch: 16 if ch == 64 else (36 if ch == 128 else 48)
     total += px * (2 * 32 + 4 * c)                       # intro: typed frame in, fp32 stream out
     for n in enc:
-        total += px * 48 * c * n
+        total += px * per_block(c) * c * n
         total += px * 4 * c + px // 4 * 4 * 2 * c         # down: read fp32 stream, write the next level's
         px, c = px // 4, 2 * c
-    total += px * 48 * c * mid
+    total += px * per_block(c) * c * mid
     for n in dec:
         total += px * 4 * c + 4 * px * (4 * c // 2) * 2   # up: read stream, write + read skip, write stream
         px, c = 4 * px, c // 2
-        total += px * 48 * c * n
+        total += px * per_block(c) * c * n
     total += px * (2 * c + 2 * c + 12) + H * W * 6        # ending: planar copy, conv, image in / out
     return total
 
