@@ -157,6 +157,22 @@ size_t pack_pointwise_weights(DType dt, const float* w, int cout, int K, uint16_
 void launch_naf_tail64(DType dt, const void* x, const float* a_scale, float* stream, long M, const void* w3, const float* b3,
                        const float* beta, const float* ln_w, const float* ln_b, float ln_eps, const void* w4, const float* b4,
                        const void* w5, const float* b5, const float* gamma, hipStream_t st);
+// naf_tail128.hip: the same second half at 128 channels, the three weight matrices streamed through LDS in eight blocks
+struct NafTail128Params {
+    const void* x;          // typed [M][ldx]: the gated tensor of the block's first half (128 channels)
+    long ldx;
+    float* stream;          // fp32 [M][lds_], updated in place
+    long lds_;
+    long M;
+    float ln_eps;
+    const void* blocks;     // pack_naf_tail128_blocks
+    void* w3_scratch;       // 2 blocks of scratch: conv3 with this forward's SCA factors folded in (written by the launcher)
+    const void* w3_scaled;  // set by the launcher
+};
+size_t naf_tail128_block_bytes();
+void launch_naf_tail128(DType dt, const NafTail128Params& p, const float* sca, hipStream_t st);
+void pack_naf_tail128_blocks(DType dt, const float* w3, const float* b3, const float* beta, const float* ln_w, const float* ln_b, const float* w4,
+                             const float* b4, const float* w5, const float* b5, const float* gamma, void* dst);
 // pointwise_gemm.hip: the many-channel form (256 x 256 tiles, LDS-DMA pipeline)
 bool pointwise_gemm_eligible(const PointwiseParams& p);
 void launch_pointwise_gemm(DType dt, const PointwiseParams& p, hipStream_t st);

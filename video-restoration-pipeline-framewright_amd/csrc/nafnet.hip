@@ -41,6 +41,8 @@ struct Block {
     DevBuf front;                                      // pw_dw_fused.hip (c = 64 / 128): parameter blocks of norm1 + conv1 + conv2, built by
                                                        // fw_nafnet_finalize from the host copies below
     std::vector<float> h_w1, h_b1, h_n1w, h_n1b, h_wdw, h_bdw;
+    DevBuf tail128;                                    // naf_tail128.hip (c = 128): the eight weight blocks of the block's second half
+    std::vector<float> h_w3, h_b3, h_beta, h_n2w, h_n2b, h_w4, h_b4, h_w5, h_b5, h_gamma;
     unsigned have = 0;                                 // bit per tensor
 };
 constexpr unsigned BLOCK_ALL = (1u << 18) - 1;
@@ -148,6 +150,14 @@ void build_front(fw_nafnet* n, Block& bl) {
     upload(bl.front, pk.data(), pk.size());
 }
 
+// conv3 .. conv5 of a 128-channel block as the weight blocks of naf_tail128.hip (norm2's affine part folded into conv4)
+void build_tail128(fw_nafnet* n, Block& bl) {
+    std::vector<char> pk(naf_tail128_block_bytes());
+    pack_naf_tail128_blocks(n->dt, bl.h_w3.data(), bl.h_b3.data(), bl.h_beta.data(), bl.h_n2w.data(), bl.h_n2b.data(), bl.h_w4.data(), bl.h_b4.data(),
+                            bl.h_w5.data(), bl.h_b5.data(), bl.h_gamma.data(), pk.data());
+    upload(bl.tail128, pk.data(), pk.size());
+}
+
 void upload_conv3(DType dt, DevBuf& b, const float* w, int cout, int cin) {
     const int ct = (cout + 31) / 32, ch = (cin + 31) / 32;
     std::vector<uint16_t> pk(pack_conv3x3_weights(dt, nullptr, cout, cin, ct, ch, nullptr));
@@ -193,22 +203,23 @@ void set_block_tensor(fw_nafnet* n, Block& bl, const std::string& name, const st
     const int c = bl.c;
     auto mark = [&](int bit) { bl.have |= 1u << bit; };
     const bool front = n->fuse_front && pw_dw_eligible(c, PWDW_GATE_MUL);
+    const bool tail = n->fuse_tail && c == 128;
     if (name == "norm1.weight") { need(numel, c, key); upload(bl.n1w, d, c * 4); if (front) { bl.h_n1w.assign(d, d + numel); bl.front.release(); } mark(0); }
     else if (name == "norm1.bias") { need(numel, c, key); upload(bl.n1b, d, c * 4); if (front) { bl.h_n1b.assign(d, d + numel); bl.front.release(); } mark(1); }
-    else if (name == "norm2.weight") { need(numel, c, key); upload(bl.n2w, d, c * 4); mark(2); }
-    else if (name == "norm2.bias") { need(numel, c, key); upload(bl.n2b, d, c * 4); mark(3); }
-    else if (name == "beta") { need(numel, c, key); upload(bl.beta, d, c * 4); mark(4); }
-    else if (name == "gamma") { need(numel, c, key); upload(bl.gamma, d, c * 4); mark(5); }
+    else if (name == "norm2.weight") { need(numel, c, key); upload(bl.n2w, d, c * 4); if (tail) { bl.h_n2w.assign(d, d + numel); bl.tail128.release(); } mark(2); }
+    else if (name == "norm2.bias") { need(numel, c, key); upload(bl.n2b, d, c * 4); if (tail) { bl.h_n2b.assign(d, d + numel); bl.tail128.release(); } mark(3); }
+    else if (name == "beta") { need(numel, c, key); upload(bl.beta, d, c * 4); if (tail) { bl.h_beta.assign(d, d + numel); bl.tail128.release(); } mark(4); }
+    else if (name == "gamma") { need(numel, c, key); upload(bl.gamma, d, c * 4); if (tail) { bl.h_gamma.assign(d, d + numel); bl.tail128.release(); } mark(5); }
     else if (name == "conv1.weight") { need(numel, (size_t)2 * c * c, key); upload_pointwise(n->dt, bl.w1, d, 2 * c, c); if (n->gemm && c >= 256) upload_pointwise16(n->dt, bl.w1g, d, 2 * c, c, 0); if (front) { bl.h_w1.assign(d, d + numel); bl.front.release(); } mark(6); }
     else if (name == "conv1.bias") { need(numel, 2 * c, key); upload(bl.b1, d, 2 * c * 4); if (front) { bl.h_b1.assign(d, d + numel); bl.front.release(); } mark(7); }
     else if (name == "conv2.weight") { need(numel, (size_t)2 * c * 9, key); upload(bl.wdw, d, (size_t)2 * c * 9 * 4); if (front) { bl.h_wdw.assign(d, d + numel); bl.front.release(); } mark(8); }
     else if (name == "conv2.bias") { need(numel, 2 * c, key); upload(bl.bdw, d, 2 * c * 4); if (front) { bl.h_bdw.assign(d, d + numel); bl.front.release(); } mark(9); }
-    else if (name == "conv3.weight") { need(numel, (size_t)c * c, key); upload_pointwise(n->dt, bl.w3, d, c, c); if (n->gemm && c >= 256) upload_pointwise16(n->dt, bl.w3g, d, c, c, 0); mark(10); }
-    else if (name == "conv3.bias") { need(numel, c, key); upload(bl.b3, d, c * 4); mark(11); }
-    else if (name == "conv4.weight") { need(numel, (size_t)2 * c * c, key); upload_pointwise(n->dt, bl.w4, d, 2 * c, c); if (n->gemm && c >= 256) upload_pointwise16(n->dt, bl.w4g, d, 2 * c, c, 1); mark(12); }
-    else if (name == "conv4.bias") { need(numel, 2 * c, key); upload(bl.b4, d, 2 * c * 4); mark(13); }
-    else if (name == "conv5.weight") { need(numel, (size_t)c * c, key); upload_pointwise(n->dt, bl.w5, d, c, c); if (n->gemm && c >= 256) upload_pointwise16(n->dt, bl.w5g, d, c, c, 0); mark(14); }
-    else if (name == "conv5.bias") { need(numel, c, key); upload(bl.b5, d, c * 4); mark(15); }
+    else if (name == "conv3.weight") { need(numel, (size_t)c * c, key); upload_pointwise(n->dt, bl.w3, d, c, c); if (n->gemm && c >= 256) upload_pointwise16(n->dt, bl.w3g, d, c, c, 0); if (tail) { bl.h_w3.assign(d, d + numel); bl.tail128.release(); } mark(10); }
+    else if (name == "conv3.bias") { need(numel, c, key); upload(bl.b3, d, c * 4); if (tail) { bl.h_b3.assign(d, d + numel); bl.tail128.release(); } mark(11); }
+    else if (name == "conv4.weight") { need(numel, (size_t)2 * c * c, key); upload_pointwise(n->dt, bl.w4, d, 2 * c, c); if (n->gemm && c >= 256) upload_pointwise16(n->dt, bl.w4g, d, 2 * c, c, 1); if (tail) { bl.h_w4.assign(d, d + numel); bl.tail128.release(); } mark(12); }
+    else if (name == "conv4.bias") { need(numel, 2 * c, key); upload(bl.b4, d, 2 * c * 4); if (tail) { bl.h_b4.assign(d, d + numel); bl.tail128.release(); } mark(13); }
+    else if (name == "conv5.weight") { need(numel, (size_t)c * c, key); upload_pointwise(n->dt, bl.w5, d, c, c); if (n->gemm && c >= 256) upload_pointwise16(n->dt, bl.w5g, d, c, c, 0); if (tail) { bl.h_w5.assign(d, d + numel); bl.tail128.release(); } mark(14); }
+    else if (name == "conv5.bias") { need(numel, c, key); upload(bl.b5, d, c * 4); if (tail) { bl.h_b5.assign(d, d + numel); bl.tail128.release(); } mark(15); }
     else if (name == "sca.1.weight") { need(numel, (size_t)c * c, key); upload(bl.wsca, d, (size_t)c * c * 4); mark(16); }
     else if (name == "sca.1.bias") { need(numel, c, key); upload(bl.bsca, d, c * 4); mark(17); }
     else throw Error(FW_ERR_INVALID, "fw_nafnet_set_tensor: unknown tensor '" + key + "'");
@@ -278,6 +289,13 @@ void run_block(fw_nafnet* n, const Block& b, float* S, int H, int W, char* ws, c
     // x = SimpleGate(conv2(x)); pooled sums for SCA
     launch_dwconv3x3_gate(n->dt, T2, H, W, c, (const float*)b.wdw.p, (const float*)b.bdw.p, T3, csum, st);
     launch_sca(csum, dwconv_blocks(H, W, c), M, c, (const float*)b.wsca.p, (const float*)b.bsca.p, sca, st);
+    }
+    if (b.tail128.p) {
+        // conv3 .. conv5 of a 128-channel block in one pass: its 128 KB of weights stream through LDS (naf_tail128.hip)
+        NafTail128Params t{};
+        t.x = T3; t.ldx = c; t.stream = S; t.lds_ = c; t.M = M; t.ln_eps = 1e-6f; t.blocks = b.tail128.p; t.w3_scratch = ws + pl.w3s;
+        launch_naf_tail128(n->dt, t, sca, st);
+        return;
     }
     if (c == 64 && n->fuse_tail) {
         // the rest of the block in one pass over the stream (nn_ops.hip naf_tail64_kernel)
@@ -493,11 +511,12 @@ int fw_nafnet_finalize(fw_nafnet* n) {
     }
     for (size_t j = 0; j < n->middle_blks.size(); ++j)
         if (n->middle_blks[j].have != BLOCK_ALL) return fail(FW_ERR_INVALID, "fw_nafnet_finalize: incomplete middle_blks." + std::to_string(j));
-    if (!n->fuse_front) return FW_OK;
+    if (!n->fuse_front && !n->fuse_tail) return FW_OK;
     return guarded([&] {
         DevGuard dg(n->device);
         auto each = [&](Block& bl) {
-            if (pw_dw_eligible(bl.c, PWDW_GATE_MUL) && !bl.front.p) build_front(n, bl);
+            if (n->fuse_front && pw_dw_eligible(bl.c, PWDW_GATE_MUL) && !bl.front.p) build_front(n, bl);
+            if (n->fuse_tail && bl.c == 128 && !bl.tail128.p) build_tail128(n, bl);
         };
         for (auto& lv : n->encoders) for (Block& bl : lv) each(bl);
         for (auto& lv : n->decoders) for (Block& bl : lv) each(bl);
@@ -669,7 +688,7 @@ int fw_nafnet_destroy(fw_nafnet* n) {
     drop_graphs(n);
     auto free_block = [](Block& b) {
         for (DevBuf* d : {&b.n1w, &b.n1b, &b.n2w, &b.n2b, &b.beta, &b.gamma, &b.w1, &b.b1, &b.w3, &b.b3, &b.w4, &b.b4, &b.w5, &b.w1g, &b.w3g, &b.w4g, &b.w5g,
-                          &b.b5, &b.wdw, &b.bdw, &b.wsca, &b.bsca, &b.front})
+                          &b.b5, &b.wdw, &b.bdw, &b.wsca, &b.bsca, &b.front, &b.tail128})
             d->release();
     };
     for (auto& v : n->encoders) for (auto& b : v) free_block(b);
