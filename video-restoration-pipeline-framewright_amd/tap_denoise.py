@@ -402,7 +402,13 @@ class TAPDenoiser:
                 elif denoised is not None and denoised[i] is not None:
                     cache[i] = denoised[i]
                 else:
-                    cache[i] = self._denoise_frame_tiled_device(up(frames[i]))
+                    # a miss pulls the next FRAME_STREAMS - 1 frames of the clip through the network with it (they are needed by the
+                    # windows that follow, and whole-frame forwards overlap on their own streams: denoise_only_device)
+                    look = self.FRAME_STREAMS if only is None else 1
+                    batch = [j for j in range(i, min(n, i + look))
+                             if j not in cache and frames[j] is not None and not (denoised is not None and denoised[j] is not None)]
+                    for j, o in zip(batch, self.denoise_only_device([up(frames[j]) for j in batch])):
+                        cache[j] = o
             return cache[i]
 
         out: List = []
@@ -433,7 +439,48 @@ class TAPDenoiser:
         """Every frame (uint8 CUDA tensors) through the network with the configured tiling, no temporal window: what a rank
         computes once per owned frame before the halo exchange."""
         self._load_model()
-        return [self._denoise_frame_tiled_device(f.contiguous()) for f in frames]
+        frames = [f.contiguous() for f in frames]
+        ts = self.config.tile_size
+        whole = all(ts == 0 or ts is None or (int(f.shape[0]) <= ts and int(f.shape[1]) <= ts) for f in frames)
+        k = min(len(frames), self.FRAME_STREAMS)
+        if k <= 1 or not whole:
+            return [self._denoise_frame_tiled_device(f) for f in frames]
+        # Whole-frame forwards of independent frames: the low-resolution levels of the U-Net (a few thousand pixels, more than half of
+        # a NAFNet forward's time) occupy a fraction of the chip, so FRAME_STREAMS frames are in flight at once, each on its own
+        # stream with its own engine clone (= its own workspace).  Every frame goes through the same kernels with the same
+        # launch geometry as alone: identical outputs.
+        import torch
+        device = frames[0].device
+        workers = self._frame_workers(k, device)
+        main = torch.cuda.current_stream(device)
+        outs = [torch.empty_like(f) for f in frames]
+        start = torch.cuda.Event()
+        start.record(main)           # the frames and the output buffers are ready once the caller's stream gets here
+        for i, f in enumerate(frames):
+            wk = workers[i % k]
+            if i < k:
+                wk["stream"].wait_event(start)
+            with torch.cuda.stream(wk["stream"]):
+                wk["engine"].denoise_device(f, out=outs[i])
+            f.record_stream(wk["stream"])
+            outs[i].record_stream(wk["stream"])
+        for wk in workers:
+            ev = torch.cuda.Event()
+            ev.record(wk["stream"])
+            main.wait_event(ev)
+        return outs
+
+    FRAME_STREAMS = int(os.environ.get("FW_TAP_FRAME_STREAMS", "2"))
+
+    def _frame_workers(self, k: int, device):
+        import torch
+        ws = getattr(self, "_fworkers", None)
+        if ws is None:
+            ws = self._fworkers = []
+        while len(ws) < k:
+            eng = self._engine if not ws else self._engine.clone()
+            ws.append({"engine": eng, "stream": torch.cuda.Stream(device=device)})
+        return ws[:k]
 
     def denoise_halo_frames(self, frames: Sequence[np.ndarray], count: int, head: bool) -> List[np.ndarray]:
         """The first/last ``count`` frames of this rank's block, denoised (tiled) but not yet temporally averaged —
@@ -508,10 +555,11 @@ class TAPDenoiser:
         return result
 
     def clear_cache(self) -> None:
-        for wk in getattr(self, "_workers", None) or []:
+        for wk in (getattr(self, "_workers", None) or []) + (getattr(self, "_fworkers", None) or []):
             if wk["engine"] is not self._engine:
                 wk["engine"].close()
         self._workers = None
+        self._fworkers = None
         if self._engine is not None:
             self._engine.close()
             self._engine = None
