@@ -2,8 +2,10 @@
 (oracle/rrdbnet_ref.py + oracle/realesrganer_ref.py) and against the reference-generated golden vectors.
 
 Tolerances (stated on the [0,1] image range):
-  * f16 operands : max-abs <= 1e-3 on the un-clamped float output, PSNR >= 60 dB on uint8
-  * bf16 operands: PSNR >= 50 dB (north_star), max-abs <= 1e-2 (bf16 has 8 mantissa bits; measured ~3e-3)
+  * f16 operands (the default of every entry point and of bench.py): max-abs <= 1e-3 on the un-clamped float output - the
+    north-star bar - and PSNR >= 60 dB on uint8
+  * bf16 operands (opt-in): PSNR >= 50 dB; max-abs measures 2.6e-3 (x4) ... 3.6e-3 (x2) on the 23-block nets (8 mantissa bits), so the 1e-3 bar is an expected
+    failure for this dtype (test_bf16_operands_miss_the_1e3_bar, strict xfail) and 4e-3 is kept as a regression bound
   * vs an oracle whose weights AND activations are rounded like the kernel's: <= 2e-4 — isolates kernel bugs from
     operand rounding.
 """
@@ -52,7 +54,7 @@ def _oracle_rgb_f32(sd, frame_bgr, num_block, scale):
     return y.squeeze(0).permute(1, 2, 0).numpy()
 
 
-@pytest.mark.parametrize("dtype,tol", [("f16", 1e-3), ("bf16", 1e-2)])
+@pytest.mark.parametrize("dtype,tol", [("f16", 1e-3), pytest.param("bf16", 4e-3, id="bf16-optin-regression-bound")])
 def test_golden_trunk_and_tail(hip_lib, golden_dir, dtype, tol):
     """Input/output recorded from the reference's AESRGAN module (oracle/gen_golden.py)."""
     g = np.load(golden_dir / "rrdb_reference.npz")
@@ -71,7 +73,7 @@ def test_golden_trunk_and_tail(hip_lib, golden_dir, dtype, tol):
     eng.close()
 
 
-@pytest.mark.parametrize("dtype,max_abs,min_psnr", [("f16", 1e-3, 60.0), ("bf16", 1e-2, 50.0)])
+@pytest.mark.parametrize("dtype,max_abs,min_psnr", [("f16", 1e-3, 60.0), pytest.param("bf16", 4e-3, 50.0, id="bf16-optin-regression-bound")])
 @pytest.mark.parametrize("num_block,scale,H,W", [(23, 4, 40, 56), (6, 4, 33, 47), (23, 2, 41, 57), (3, 2, 64, 64)])
 def test_rrdbnet_vs_oracle(hip_lib, dtype, max_abs, min_psnr, num_block, scale, H, W):
     sd = synthetic_rrdbnet_state(num_block, scale, seed=1234)
@@ -90,6 +92,18 @@ def test_rrdbnet_vs_oracle(hip_lib, dtype, max_abs, min_psnr, num_block, scale, 
     assert psnr >= min_psnr
     assert np.abs(u8.astype(int) - want_u8.astype(int)).max() <= (1 if dtype == "f16" else 3)
     eng.close()
+
+
+@pytest.mark.xfail(strict=True, reason="bf16 operands are opt-in: 2.6e-3 max-abs on the 23-block x4 net (8 mantissa bits); the 1e-3 bar "
+                                      "is met by f16, the default dtype of every entry point and of bench.py")
+def test_bf16_operands_miss_the_1e3_bar(hip_lib):
+    sd = synthetic_rrdbnet_state(23, 4, seed=1234)
+    frame = synthetic_frames(1, 40, 56, seed=40 * 56)[0]
+    eng = R.RRDBNetEngine(23, 4, "bf16")
+    eng.load_state_dict(sd)
+    rgb, _ = _gpu_rgb_f32(eng, frame)
+    eng.close()
+    assert np.abs(rgb - _oracle_rgb_f32(sd, frame, 23, 4)).max() < 1e-3
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])

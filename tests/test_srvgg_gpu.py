@@ -1,6 +1,7 @@
 """SRVGGNetCompact (realesr-animevideov3 / realesr-general-x4v3) on the GPU against the fp32 CPU oracle
 (oracle/srvgg_ref.py; parity unpinned at the third-party boundary, see its header).  Tolerances as for the RRDBNet path:
-f16 operands 1e-3 max-abs on the [0,1] float output, bf16 operands 1e-2 and PSNR >= 50 dB."""
+f16 operands (the default) 1e-3 max-abs on the [0,1] float output; bf16 operands are opt-in: 1e-2 and PSNR >= 50 dB are regression
+bounds for that dtype, not the parity bar."""
 import math
 
 import numpy as np
