@@ -95,14 +95,13 @@ def lib_digest():
 
 def nafnet_design_bytes(H, W, width=64, enc=(2, 2, 4, 8), mid=12, dec=(2, 2, 2, 2)):
     """HBM bytes one NAFNet forward moves in THIS engine's dataflow, every tensor counted once per kernel that reads or writes
-    it.  Per NAFBlock and pixel, c channels: 16c at c = 64 (two kernels: the fused front reads the fp32
-    stream and writes the gated tensor, the fused tail reads both and writes the stream), 36c at c = 128 (fused front, then conv3 /
-    LayerNorm / conv4 + gate / conv5 as four passes), 48c from 256 channels up (seven passes: fp32 stream read twice and written
+    it.  Per NAFBlock and pixel, c channels: 16c at c = 64 and 128 (two kernels: the fused front reads the
+    fp32 stream and writes the gated tensor, the fused tail reads both and writes the stream), 48c from 256 channels up (seven passes: fp32 stream read twice and written
     twice, five typed tensors - the round-1 figure for every level); plus the 2x2 down convs, the 1x1 + PixelShuffle ups, intro
     and ending."""
     Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
     px, c, total = Hp * Wp, width, 0.0
-    per_block = lambda ch: 16 if ch == 64 else (36 if ch == 128 else 48)
+    per_block = lambda ch: 16 if ch <= 128 else 48
     total += px * (2 * 32 + 4 * c)                       # intro: typed frame in, fp32 stream out
     for n in enc:
         total += px * per_block(c) * c * n
@@ -236,7 +235,7 @@ def main():
                 frames.append(frame_of(k))
             else:
                 frames.append(frame_of(k) if rank == world - 1 else None)
-            S.sharded_pairs(frames, lambda a, b: ifn.interpolate_device(a.to(dev), b.to(dev), 0.5, out=out_if), device=halo_dev)
+            S.sharded_interpolate_device(ifn, frames, halo_device=halo_dev)
         elif cfg == "tap":
             S.sharded_tap_denoise_device(tap, global_list([frame_of(i) for i in range(k)]), halo_device=halo_dev)
         else:

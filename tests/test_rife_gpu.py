@@ -220,3 +220,23 @@ def test_interpolate_smoothness_scene_cuts_and_streaming(hip_lib, tmp_path, monk
         assert np.array_equal(x, unsharp_ref.unsharp_mask_u8(y, 2, 100, 3))
     with pytest.raises(RF.InterpolationError):
         low.interpolate_frames(tmp_path / "in_none", tmp_path / "o")
+
+
+def test_pairs_in_flight_on_streams_equal_one_at_a_time(hip_lib):
+    """IFNetEngine.interpolate_pairs_device: several pairs overlapped on their own streams and engine clones give the frames the
+    pairs give one after the other (same kernels, same launch geometry), in order, for more pairs than streams."""
+    fr = [torch.from_numpy(f).cuda() for f in synthetic_frames(6, 270, 480, seed=21)]
+    eng = RF.IFNetEngine("f16")
+    eng.load_state_dict(synthetic_ifnet_state())
+    pairs = [(fr[i], fr[i + 1]) for i in range(5)]
+    want = [eng.interpolate_device(a, b, 0.5).clone() for a, b in pairs]
+    torch.cuda.synchronize()
+    for _ in range(2):                                       # second call: the clones exist already
+        got = eng.interpolate_pairs_device(pairs, 0.5)
+        torch.cuda.synchronize()
+        assert len(got) == 5 and all(torch.equal(g, w) for g, w in zip(got, want))
+    assert eng.interpolate_pairs_device([], 0.5) == []
+    one = eng.interpolate_pairs_device(pairs[:1], 0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(one[0], want[0])
+    eng.close()

@@ -135,9 +135,10 @@ def sharded_temporal_denoise(frames: Sequence, radius: int, denoise_one: Callabl
     return out
 
 
-def sharded_pairs(frames: Sequence, interp_pair: Callable, device="cpu") -> Dict[int, object]:
+def sharded_pairs(frames: Sequence, interp_pair: Callable, device="cpu", interp_many: Optional[Callable] = None) -> Dict[int, object]:
     """RIFE x2: mid-frames of the pairs (i, i+1) whose left frame this rank owns; the right neighbour's first INPUT frame is
-    the halo (a tensor on ``device`` when the inputs are tensors)."""
+    the halo (a tensor on ``device`` when the inputs are tensors).  ``interp_many([(a, b), ...]) -> [mid, ...]``, when given, gets
+    all of this rank's pairs in one call (IFNetEngine.interpolate_pairs_device overlaps them on streams)."""
     import torch
     rank, world = _dist_info()
     n = len(frames)
@@ -154,13 +155,15 @@ def sharded_pairs(frames: Sequence, interp_pair: Callable, device="cpu") -> Dict
         _, nxt = exchange_with_neighbours(send_prev, None, None, (1,) + tuple(f0.shape) if want_next else None, device)
         if nxt is not None:
             halo = nxt[0].cpu().numpy() if as_numpy else nxt[0]
-    out: Dict[int, object] = {}
+    todo = []
     for i in range(lo, hi):
         if i + 1 < hi:
-            out[i] = interp_pair(frames[i], frames[i + 1])
+            todo.append((i, frames[i], frames[i + 1]))
         elif i + 1 < n:
-            out[i] = interp_pair(frames[i], halo if halo is not None else frames[i + 1])
-    return out
+            todo.append((i, frames[i], halo if halo is not None else frames[i + 1]))
+    if interp_many is not None:
+        return dict(zip([i for i, _, _ in todo], interp_many([(a, b) for _, a, b in todo])))
+    return {i: interp_pair(a, b) for i, a, b in todo}
 
 
 def sharded_tap_denoise_device(tap, frames: Sequence, halo_device=None) -> Dict[int, object]:
@@ -203,4 +206,5 @@ def sharded_interpolate_device(engine, frames: Sequence, halo_device=None) -> Di
     lo, hi = block_partition(len(frames), world)[rank]
     fr = [_as_tensor(f, dev) if (lo <= i < hi or (world == 1 and f is not None)) and f is not None else None for i, f in enumerate(frames)]
     hd = dev if halo_device is None else torch.device(halo_device)
-    return sharded_pairs(fr, lambda a, b: engine.interpolate_device(a.to(dev), b.to(dev), 0.5), device=hd)
+    return sharded_pairs(fr, lambda a, b: engine.interpolate_device(a.to(dev), b.to(dev), 0.5), device=hd,
+                         interp_many=lambda ps: engine.interpolate_pairs_device([(a.to(dev), b.to(dev)) for a, b in ps], 0.5))

@@ -402,9 +402,9 @@ class TAPDenoiser:
                 elif denoised is not None and denoised[i] is not None:
                     cache[i] = denoised[i]
                 else:
-                    # a miss pulls the next FRAME_STREAMS - 1 frames of the clip through the network with it (they are needed by the
+                    # a miss pulls the next FW_TAP_FRAME_STREAMS - 1 frames of the clip through the network with it (they are needed by the
                     # windows that follow, and whole-frame forwards overlap on their own streams: denoise_only_device)
-                    look = self.FRAME_STREAMS if only is None else 1
+                    look = _lib.side_streams("FW_TAP_FRAME_STREAMS", 2) if only is None else 1
                     batch = [j for j in range(i, min(n, i + look))
                              if j not in cache and frames[j] is not None and not (denoised is not None and denoised[j] is not None)]
                     for j, o in zip(batch, self.denoise_only_device([up(frames[j]) for j in batch])):
@@ -442,11 +442,11 @@ class TAPDenoiser:
         frames = [f.contiguous() for f in frames]
         ts = self.config.tile_size
         whole = all(ts == 0 or ts is None or (int(f.shape[0]) <= ts and int(f.shape[1]) <= ts) for f in frames)
-        k = min(len(frames), self.FRAME_STREAMS)
+        k = min(len(frames), _lib.side_streams("FW_TAP_FRAME_STREAMS", 2))
         if k <= 1 or not whole:
             return [self._denoise_frame_tiled_device(f) for f in frames]
         # Whole-frame forwards of independent frames: the low-resolution levels of the U-Net (a few thousand pixels, more than half of
-        # a NAFNet forward's time) occupy a fraction of the chip, so FRAME_STREAMS frames are in flight at once, each on its own
+        # a NAFNet forward's time) occupy a fraction of the chip, so FW_TAP_FRAME_STREAMS (default 2) frames are in flight at once, each on its own
         # stream with its own engine clone (= its own workspace).  Every frame goes through the same kernels with the same
         # launch geometry as alone: identical outputs.
         import torch
@@ -469,8 +469,6 @@ class TAPDenoiser:
             ev.record(wk["stream"])
             main.wait_event(ev)
         return outs
-
-    FRAME_STREAMS = int(os.environ.get("FW_TAP_FRAME_STREAMS", "2"))
 
     def _frame_workers(self, k: int, device):
         import torch
