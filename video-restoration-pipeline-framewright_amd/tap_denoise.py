@@ -299,7 +299,7 @@ class TAPDenoiser:
         _lib.check(lib.fw_tile_blend_finish(p(acc), p(wsum), h, w, p(out), C.c_void_p(main.cuda_stream)))
         return out
 
-    TILE_STREAMS = int(os.environ.get("FW_TAP_TILE_STREAMS", "6"))
+    TILE_STREAMS = int(os.environ.get("FW_TAP_TILE_STREAMS", "3"))   # tools/time_tiled.py: 1 / 2 / 3 / 4 / 6 streams = 72 / 42 / 32 / 44 / 33 ms (NAFNet), 169 / 168 / 114 / 115 / 121 (Restormer)
 
     def _tile_workers(self, k: int, device, ts: int):
         import torch
