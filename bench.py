@@ -318,7 +318,17 @@ def main():
             ms = e0.elapsed_time(e1) / reps
             nbytes = nafnet_design_bytes(H, W) if cfg == "tap" else ifnet_design_bytes(H, W)
             gbs = nbytes / (ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+            traffic, note = None, None
+            tf = ROOT / "profiles" / "r02_traffic_tap.json"
+            if cfg == "tap" and tf.exists() and (H, W) == (1080, 1920):
+                tj = json.loads(tf.read_text())
+                if tj.get("lib_digest") == lib_digest() and tj.get("dtype") == args.dtype:
+                    traffic = tj["hbm_bytes_per_forward"]
+                    note = f"profiles/r02_traffic_tap.json, PMC counters of this build ({tj['lib_digest']}): {traffic / 1e9:.1f} GB per forward"
+                else:
+                    note = "profiles/r02_traffic_tap.json was measured on another build or dtype: not quoted"
+            roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": traffic,
+                    "traffic_source": note,
                     "kernel": "one NAFNet-width64 forward (all kernels)" if cfg == "tap" else "one IFNet v4.6 forward (all kernels)",
                     "forward_ms": ms, "bytes_per_forward": nbytes,
                     "flops_per_forward": (naf.flops(H, W) if cfg == "tap" else ifn.flops(H, W))}

@@ -11,3 +11,4 @@ for c in sr tap rife restormer; do
 done
 cp $o/pmc_summary.json profiles/r02_pmc_summary.json
 cp $o/r02_traffic.json profiles/r02_traffic.json
+cp $o/r02_traffic_tap.json $o/r02_traffic_restormer.json profiles/
