@@ -28,7 +28,18 @@
 namespace fw {
 
 template <typename T, int CT, int EPI>
-__global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kernel(const ConvParams p_in) {
+    ConvParams p = p_in;
+    if constexpr (EPI == EPI_STORE || EPI == EPI_RESIDUAL) {
+        if (p_in.n_groups > 1) {   // grid.y = output-channel group of a wide conv (scalar pointer arithmetic, once per workgroup)
+            const int g = blockIdx.y;
+            p.wpk = reinterpret_cast<const char*>(p_in.wpk) + (size_t)g * p_in.wpk_gstride;
+            p.bias = p_in.bias + 32 * CT * g;
+            if (p_in.chan_scale) p.chan_scale = p_in.chan_scale + 32 * CT * g;
+            p.out_coff = p_in.out_coff + 32 * CT * g;
+            p.f32_coff = p_in.f32_coff + 32 * CT * g;
+        }
+    }
     using SM = Smem<CT>;
     __shared__ __attribute__((aligned(16))) uint4 lds[SM::TOTAL];
     constexpr int NA = SM::NA;
@@ -499,7 +510,9 @@ template <typename T>
 static void launch_typed(int cout_tiles, ConvEpilogue epi, const ConvParams& p, hipStream_t stream) {
     const int tiles = ((p.W + TILE_W - 1) / TILE_W) * ((p.H + TILE_H - 1) / TILE_H);
     // persistent workgroups: one per CU (LDS-limited), each walks a contiguous range of tiles
-    dim3 grid(tiles < num_cus() ? tiles : num_cus()), block(64 * NWAVES);
+    const int ng = p.n_groups > 1 ? p.n_groups : 1;
+    const int per_group = num_cus() / ng > 0 ? num_cus() / ng : 1;
+    dim3 grid(tiles < per_group ? tiles : per_group, ng), block(64 * NWAVES);
     if (cout_tiles == 1 && epi == EPI_STORE)
         hipLaunchKernelGGL((conv3x3_mfma_kernel<T, 1, EPI_STORE>), grid, block, 0, stream, p);
     else if (cout_tiles == 2 && epi == EPI_STORE)
@@ -533,6 +546,8 @@ void launch_conv3x3(DType dt, int cout_tiles, ConvEpilogue epi, const ConvParams
         throw Error(1, "conv3x3: bad output plane stride");
     if (p.out && ((p.out_cstride & 7) || (p.out_coff & 7))) throw Error(1, "conv3x3: output slice must be 16-byte aligned");
     if (p.act == 2 && !p.chan_scale) throw Error(1, "conv3x3: PReLU needs its slopes");
+    if (p.n_groups > 1 && ((epi != EPI_STORE && epi != EPI_RESIDUAL) || p.n_groups > 64 || p.wpk_gstride <= 0 || (p.wpk_gstride & 15) || p.f32_native))
+        throw Error(1, "conv3x3: output-channel groups need EPI_STORE / EPI_RESIDUAL and a 16-byte weight stride");
     if (p.out_lo && (cout_tiles != 2 || !p.out || epi == EPI_IMAGE)) throw Error(1, "conv3x3: out_lo needs a 64-channel typed output");
     if (epi == EPI_RESIDUAL_SPLIT) {
         if (cout_tiles != 2 || p.upsample2x || !p.out || p.n_id < 0 || p.n_id > 6 || p.n_id > p.cin_chunks)

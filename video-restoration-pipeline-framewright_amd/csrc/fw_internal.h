@@ -67,6 +67,11 @@ struct ConvParams {
     long chunk_off[6];     // EPI_RESIDUAL_SPLIT: byte offset of residual plane c from `in`; pixel stride = in_cstride
     unsigned long long* stamps;  // diagnostic builds only (-DFW_PAIR_STAMP)
     const void* zeros;     // >= 16 bytes of zeros in device memory (set by launch_conv3x3)
+    // EPI_STORE / EPI_RESIDUAL: n_groups > 1 runs that many convolutions of 32 * cout_tiles output channels each in ONE launch
+    // (grid.y = group): group g reads its weights wpk_gstride bytes further on and shifts bias, chan_scale, out_coff and f32_coff
+    // by 32 * cout_tiles * g - the output-channel groups of a wide conv on a small feature map side by side (IFNet)
+    int n_groups;
+    long wpk_gstride;
 };
 
 // Number of floats of an accumulator-native fp32 side buffer for an H x W problem with 32*cout_tiles channels:

@@ -58,12 +58,17 @@ struct Conv {
         int ct = 0, off = 0;
     };
     std::vector<Group> groups;
+    DevBuf wall, ball;       // every group's weights / biases in one buffer each, when all groups are 64 channels wide:
+    size_t gstride = 0;      // the groups then run side by side in one launch (ConvParams::n_groups)
     void release() {
         for (auto& g : groups) {
             g.w.release();
             g.b.release();
         }
         groups.clear();
+        wall.release();
+        ball.release();
+        gstride = 0;
     }
     // w: [cout][cin][3][3] fp32 (already transformed), zero-padded to [cout_pad][cin_pad]
     void build(DType dt, const std::vector<float>& w, const std::vector<float>& b, int cout, int cin, int cin_p, int cout_p) {
@@ -88,6 +93,16 @@ struct Conv {
             upload(g.w, pk.data(), pk.size() * 2);
             upload(g.b, bp.data() + off, (size_t)32 * ct * 4);
             off += 32 * ct;
+        }
+        if (groups.size() > 1 && cout_p % 64 == 0) {
+            const int chunks = cin_p / 32;
+            const size_t n = pack_conv3x3_weights(dt, nullptr, 64, cin_p, 2, chunks, nullptr);
+            std::vector<uint16_t> all(n * groups.size());
+            for (size_t g = 0; g < groups.size(); ++g)
+                pack_conv3x3_weights(dt, wp.data() + g * 64 * cin_p * 9, 64, cin_p, 2, chunks, all.data() + g * n);
+            upload(wall, all.data(), all.size() * 2);
+            upload(ball, bp.data(), bp.size() * 4);
+            gstride = n * 2;
         }
     }
 };
@@ -153,6 +168,7 @@ struct fw_ifnet {
     // hipGraph replay of a forward, keyed by everything a captured launch sequence bakes in (FW_IFNET_GRAPH=1; off by default:
     // a caller that hands over fresh buffers every frame would re-capture every frame)
     int graph_mode = 0;
+    bool merge_groups = true;   // the 64-channel output groups of a conv in one launch (FW_IFNET_MERGE_GROUPS=0: A/B)
     bool warmed = false;
     struct GraphEntry {
         int H, W;
@@ -242,7 +258,9 @@ Plan make_plan(int H, int W) {
 
 void run_conv(const fw_ifnet* n, const Conv& cv, const void* x, int h, int w, void* out, float* out_f32, int act, const float* res,
               const float* beta, int post_act, hipStream_t st) {
+    const bool merged = n->merge_groups && cv.wall.p;
     for (const auto& g : cv.groups) {
+        if (merged && g.off > 0) break;   // group 0's launch carries all of them
         ConvParams p{};
         p.in = x;
         p.in_cstride = cv.cin_pad;
@@ -265,6 +283,12 @@ void run_conv(const fw_ifnet* n, const Conv& cv, const void* x, int h, int w, vo
         p.post_act = post_act;
         p.f32_cstride = cv.cout_pad;
         p.f32_coff = g.off;
+        if (merged) {
+            p.wpk = cv.wall.p;
+            p.bias = (const float*)cv.ball.p;
+            p.n_groups = (int)cv.groups.size();
+            p.wpk_gstride = (long)cv.gstride;
+        }
         launch_conv3x3(n->dt, g.ct, res ? EPI_RESIDUAL : EPI_STORE, p, st);
     }
 }
@@ -335,6 +359,7 @@ int fw_ifnet_create(int device_id, int dtype, fw_ifnet** out) {
         n->device = device_id;
         n->dt = (DType)dtype;
         if (const char* e = getenv("FW_IFNET_GRAPH")) n->graph_mode = atoi(e);
+        if (const char* e = getenv("FW_IFNET_MERGE_GROUPS")) n->merge_groups = atoi(e) != 0;
         for (int i = 0; i < NBLK; ++i) {
             Block& b = n->blk[i];
             b.c = CH[i];
