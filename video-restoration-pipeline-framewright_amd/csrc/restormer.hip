@@ -64,9 +64,13 @@ int upload_pointwise(DType dt, DevBuf& b, const float* w, int cout, int k, int k
 struct Conv3 {
     int cin_pad = 0, cout_pad = 0;
     std::vector<DevBuf> groups;
+    DevBuf wall;            // all groups in one buffer, gstride bytes apart: they run side by side in one launch (ConvParams::n_groups)
+    size_t gstride = 0;
     void release() {
         for (auto& g : groups) g.release();
         groups.clear();
+        wall.release();
+        gstride = 0;
     }
     void build(DType dt, const float* w, int cout, int cin, int cin_pad_or_0) {
         release();
@@ -77,12 +81,16 @@ struct Conv3 {
             for (int ci = 0; ci < cin; ++ci)
                 for (int t = 0; t < 9; ++t) wp[((size_t)co * cin_pad + ci) * 9 + t] = w[((size_t)co * cin + ci) * 9 + t];
         const int chunks = cin_pad / 32;
+        std::vector<uint16_t> all;
         for (int off = 0; off < cout_pad; off += 64) {
             std::vector<uint16_t> pk(pack_conv3x3_weights(dt, nullptr, 64, cin_pad, 2, chunks, nullptr));
             pack_conv3x3_weights(dt, wp.data() + (size_t)off * cin_pad * 9, 64, cin_pad, 2, chunks, pk.data());
             groups.emplace_back();
             upload(groups.back(), pk.data(), pk.size() * 2);
+            gstride = pk.size() * 2;
+            all.insert(all.end(), pk.begin(), pk.end());
         }
+        if (groups.size() > 1) upload(wall, all.data(), all.size() * 2);
     }
 };
 
@@ -131,6 +139,7 @@ struct fw_restormer {
     DevBuf red3, red2, conv_bias, ones;
     int red3_t = 0, red2_t = 0;
     bool built = false;
+    bool merge_groups = true; // the 64-channel output groups of a 3x3 conv in one launch (FW_REST_MERGE_GROUPS=0: A/B)
     bool qk_direct = true;    // the fused qkv front writes q / k in the Gram kernel's operand layout (FW_REST_QK_DIRECT=0: pixel-major + transpose pass)
     bool merge_proj = true;   // project_out folded into the attention matrix: one GEMM pass instead of two (FW_REST_MERGE_PROJ=0: A/B)
     bool fuse_front = true;   // LayerNorm + 1x1 + depthwise 3x3 (+ GDFN gate) of the 48- / 96-channel blocks as one kernel (FW_REST_FUSE_FRONT=0: A/B)
@@ -194,9 +203,18 @@ void forward(fw_restormer* n, Arena& A, const uint8_t* d_in, int H, int W, uint8
         const size_t mark = A.top;
         void* xp = typ((size_t)cv.cin_pad * M);
         RUN(fw_f32_to_planar(dt, x, M, cv.cin_pad, xp, st));
-        for (size_t g = 0; g < cv.groups.size(); ++g)
-            RUN(fw_conv3x3_nhwc_ex(dt, xp, 32, M * 32, cv.cin_pad / 32, h, w, cv.groups[g].p, (const float*)n->conv_bias.p, 2, 0, 0, nullptr,
-                                   1.f, nullptr, 1.f, nullptr, 0, cv.cout_pad, (int)g * 64, nullptr, 32, 0, 0, y, st));
+        if (cv.wall.p && n->merge_groups && cv.groups.size() <= 64) {
+            // the 64-channel output groups side by side in one launch (the up convs have 3 / 6 / 12 of them on 64 ... 16 k pixels)
+            ConvParams p{};
+            p.in = xp; p.in_cstride = 32; p.in_pstride = M * 32; p.out_pstride = 32; p.cin_chunks = cv.cin_pad / 32; p.H = h; p.W = w;
+            p.wpk = cv.wall.p; p.bias = (const float*)n->conv_bias.p; p.out_f32 = y; p.s1 = p.s2 = 1.f; p.f32_cstride = cv.cout_pad;
+            p.n_groups = (int)cv.groups.size(); p.wpk_gstride = (long)cv.gstride;
+            if (run) launch_conv3x3(n->dt, 2, EPI_STORE, p, st_);
+        } else {
+            for (size_t g = 0; g < cv.groups.size(); ++g)
+                RUN(fw_conv3x3_nhwc_ex(dt, xp, 32, M * 32, cv.cin_pad / 32, h, w, cv.groups[g].p, (const float*)n->conv_bias.p, 2, 0, 0, nullptr,
+                                       1.f, nullptr, 1.f, nullptr, 0, cv.cout_pad, (int)g * 64, nullptr, 32, 0, 0, y, st));
+        }
         A.top = mark;
     };
 
@@ -357,6 +375,7 @@ int fw_restormer_create(int device_id, int dim, const int* num_blocks, int num_r
         if (const char* e = getenv("FW_REST_FUSE_FRONT")) n->fuse_front = atoi(e) != 0;
         if (const char* e = getenv("FW_REST_MERGE_PROJ")) n->merge_proj = atoi(e) != 0;
         if (const char* e = getenv("FW_REST_QK_DIRECT")) n->qk_direct = atoi(e) != 0;
+        if (const char* e = getenv("FW_REST_MERGE_GROUPS")) n->merge_groups = atoi(e) != 0;
         for (int i = 0; i < 4; ++i) {
             if (num_blocks[i] < 0 || num_blocks[i] > 64 || heads[i] < 1) throw Error(FW_ERR_INVALID, "fw_restormer_create: bad block / head counts");
             n->nblk[i] = num_blocks[i];
@@ -485,7 +504,7 @@ int fw_restormer_finalize(fw_restormer* n) {
             n->convs[GLOBAL_CONV3[k]].build(dt, n->host.at(GLOBAL_CONV3[k]).data(), couts[k], cins[k], k == 0 ? 32 : 0);
         n->red3_t = upload_pointwise(dt, n->red3, n->host.at("reduce_chan_level3.weight").data(), 4 * d, 8 * d, 8 * d);
         n->red2_t = upload_pointwise(dt, n->red2, n->host.at("reduce_chan_level2.weight").data(), 2 * d, 4 * d, 4 * d);
-        std::vector<float> z(64, 0.f), o(2048, 1.f);
+        std::vector<float> z(64 * 64, 0.f), o(2048, 1.f);   // zero bias for up to 64 output-channel groups in one launch
         upload(n->conv_bias, z.data(), z.size() * 4);
         upload(n->ones, o.data(), o.size() * 4);
         n->host.clear();
