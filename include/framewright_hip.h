@@ -53,7 +53,8 @@ typedef struct fw_nafnet fw_nafnet;
 /* Message of the last failing call on this thread ("" if none).  Never NULL. */
 const char* fw_last_error(void);
 
-/* ABI version of this header: 2.  Bumped whenever entry points are added or changed (1 -> 2 was additive). */
+/* ABI version of this header: 3.  Bumped whenever entry points are added or changed (1 -> 2 and 2 -> 3 were additive: a binder of
+ * version 1 or 2 keeps working against this library). */
 int fw_abi_version(void);
 
 /* Number of visible HIP devices (0 when there is no GPU; never fails). */
@@ -382,6 +383,22 @@ int fw_ifnet_blend(const float* img0, const float* img1, const float* flow, cons
  * scratch_a / scratch_b: two H*W*C-byte device buffers.  `out` may alias `src`. */
 int fw_unsharp_mask_u8(const uint8_t* src, int height, int width, int channels, int box_radius, unsigned ww, unsigned fw_weight,
                        int passes, int percent, int threshold, uint8_t* scratch_a, uint8_t* scratch_b, uint8_t* out, void* stream);
+
+/* ---- SRVGGNetCompact as one engine (csrc/srvgg.hip) ---------------------------------------------------------------------------
+ * The network of the Real-ESRGAN checkpoints realesr-animevideov3 (num_conv 16) / realesr-general-x4v3 (num_conv 32), which the
+ * reference lists in its model table (processors/pytorch_realesrgan.py:119-128): create, hand over the tensors of the published
+ * state dict (body.{2i}.weight [cout][cin][3][3], body.{2i}.bias, body.{2i+1}.weight = PReLU slopes [64]), finalize, then any number
+ * of fw_srvgg_upscale_u8 calls (uint8 BGR H x W x 3 in, uint8 BGR sH x sW x 3 and / or RGB float out; FW_HOST or FW_DEVICE buffers).
+ * One handle per GPU; calls on a handle are serialised by an internal mutex. */
+typedef struct fw_srvgg fw_srvgg;
+int fw_srvgg_create(int device_id, int num_feat, int num_conv, int upscale, int dtype, fw_srvgg** out);
+int fw_srvgg_set_tensor(fw_srvgg* net, const char* key, const float* data, size_t numel);
+int fw_srvgg_finalize(fw_srvgg* net);
+int fw_srvgg_upscale_u8(fw_srvgg* net, const uint8_t* in_bgr, int in_loc, int height, int width, uint8_t* out_bgr, int out_loc,
+                        float* out_rgb_f32, void* stream);
+size_t fw_srvgg_workspace_bytes(const fw_srvgg* net, int height, int width);
+double fw_srvgg_flops(const fw_srvgg* net, int height, int width);
+int fw_srvgg_destroy(fw_srvgg* net);
 
 /* ---- IFNet v4.6 (RIFE x2 interpolation) as one engine ------------------------------------------------------------------------
  * Replaces the reference's `rife-ncnn-vulkan` subprocess (reference src/framewright/processors/interpolation.py:628-650; model

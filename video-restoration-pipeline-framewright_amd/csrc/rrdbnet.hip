@@ -454,7 +454,8 @@ extern "C" {
 
 const char* fw_last_error(void) { return fw::last_error_ref().c_str(); }
 
-int fw_abi_version(void) { return 2; }  // 2: + upscale_u16, resize_lanczos4, grain_addback, attention (softmax rows, transposed pack, MFMA Gram)
+int fw_abi_version(void) { return 3; }  // 2: + upscale_u16, resize_lanczos4, grain_addback, attention (softmax rows, transposed pack, MFMA Gram)
+                                         // 3 (round 2, additive): + fw_ifnet_*, fw_restormer_*, fw_srvgg_*, fw_unsharp_mask_u8, fw_preserve_edges_*, fw_attn_proj_pack
 
 int fw_device_count(void) {
     int n = 0;

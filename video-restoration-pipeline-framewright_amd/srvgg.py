@@ -75,7 +75,9 @@ def _to_numpy(t) -> np.ndarray:
 
 
 class SRVGGNetEngine:
-    """SRVGGNetCompact resident on one GPU; same surface as RRDBNetEngine (load_state_dict / upscale_device / flops)."""
+    """SRVGGNetCompact resident on one GPU; same surface as RRDBNetEngine (load_state_dict / upscale_device / flops).  Thin owner of
+    an ``fw_srvgg*`` (csrc/srvgg.hip): weight packing, the workspace and the launches of a forward live behind the C-ABI
+    (``fw_srvgg_upscale_u8``), serialised per handle by its mutex."""
 
     def __init__(self, num_conv: int, scale: int = 4, dtype: str = "f16", device_id: int = 0):
         import torch
@@ -83,80 +85,53 @@ class SRVGGNetEngine:
         _lib.require_gpu()
         if scale not in (1, 2, 3, 4) or 3 * scale * scale > 64:
             raise ValueError("SRVGGNetEngine: scale must be 1..4")
+        if dtype not in _lib.DTYPES:
+            raise ValueError(f"dtype must be one of {sorted(_lib.DTYPES)}")
         self.num_conv, self.scale, self.dtype, self.device_id = int(num_conv), int(scale), dtype, int(device_id)
-        self._dt = _lib.DTYPES[dtype]
-        self._tdt = torch.float16 if self._dt == _lib.FW_DTYPE_F16 else torch.bfloat16
         self._dev = torch.device("cuda", self.device_id)
-        self._layers: List[Tuple[object, object, Optional[object], int]] = []   # packed w, bias, slopes, cin chunks
+        h = C.c_void_p()
+        _lib.check(self._lib.fw_srvgg_create(self.device_id, NUM_FEAT, self.num_conv, self.scale, _lib.DTYPES[dtype], C.byref(h)))
+        self._h = h
+        self._loaded = False
 
     def load_state_dict(self, state: Mapping[str, object]) -> None:
-        import torch
-        lib = self._lib
         state = unwrap_state(state)
-        layers = []
-        for i in range(self.num_conv + 2):
-            wk, bk, pk = f"body.{2 * i}.weight", f"body.{2 * i}.bias", f"body.{2 * i + 1}.weight"
-            for k in (wk, bk) + ((pk,) if i < self.num_conv + 1 else ()):
-                if k not in state:
-                    raise FramewrightHipError(_lib.FW_ERR_INVALID, f"state dict is missing {k}")
-            w = np.ascontiguousarray(_to_numpy(state[wk]), dtype=np.float32)
-            b = np.ascontiguousarray(_to_numpy(state[bk]), dtype=np.float32)
-            cin = 3 if i == 0 else NUM_FEAT
-            cout = 3 * self.scale ** 2 if i == self.num_conv + 1 else NUM_FEAT
-            if w.shape != (cout, cin, 3, 3) or b.shape != (cout,):
-                raise FramewrightHipError(_lib.FW_ERR_INVALID, f"{wk}: expected shape {(cout, cin, 3, 3)}, got {w.shape}")
-            chunks = (cin + 31) // 32
-            wp = np.zeros((64, 32 * chunks, 3, 3), np.float32)
-            wp[:cout, :cin] = w
-            bp = np.zeros((64,), np.float32)
-            bp[:cout] = b
-            n = lib.fw_pack_conv3x3(self._dt, None, 64, 32 * chunks, 2, chunks, None)
-            buf = np.zeros(n, np.uint16)
-            if lib.fw_pack_conv3x3(self._dt, C.c_void_p(wp.ctypes.data), 64, 32 * chunks, 2, chunks,
-                                   C.c_void_p(buf.ctypes.data)) != n:
-                raise FramewrightHipError(_lib.FW_ERR_INTERNAL, "fw_pack_conv3x3 failed")
-            slopes = None
-            if i < self.num_conv + 1:
-                sl = np.ascontiguousarray(_to_numpy(state[pk]), dtype=np.float32).reshape(-1)
-                if sl.shape != (NUM_FEAT,):
-                    raise FramewrightHipError(_lib.FW_ERR_INVALID, f"{pk}: expected shape ({NUM_FEAT},), got {sl.shape}")
-                slopes = torch.from_numpy(sl).to(self._dev)
-            layers.append((torch.from_numpy(buf.view(np.int16)).to(self._dev), torch.from_numpy(bp).to(self._dev), slopes, chunks))
-        self._layers = layers
+        for key, shape in srvgg_tensor_shapes(self.num_conv, self.scale):
+            if key not in state:
+                raise FramewrightHipError(_lib.FW_ERR_INVALID, f"state dict is missing {key}")
+            a = np.ascontiguousarray(_to_numpy(state[key]), dtype=np.float32)
+            if a.ndim == 1 and len(shape) == 1:
+                a = a.reshape(-1)
+            if tuple(a.shape) != tuple(shape):
+                raise FramewrightHipError(_lib.FW_ERR_INVALID, f"{key}: expected shape {shape}, got {a.shape}")
+            _lib.check(self._lib.fw_srvgg_set_tensor(self._h, key.encode(), C.c_void_p(a.ctypes.data), a.size))
+        _lib.check(self._lib.fw_srvgg_finalize(self._h))
+        self._loaded = True
 
     def flops(self, H: int, W: int) -> float:
-        mac = 9.0 * (3 * NUM_FEAT + self.num_conv * NUM_FEAT * NUM_FEAT + NUM_FEAT * 3 * self.scale ** 2)
-        return 2.0 * mac * H * W
+        return float(self._lib.fw_srvgg_flops(self._h, H, W))
 
     @_lib.on_tensor_device
     def upscale_device(self, frame_bgr, out=None, out_rgb_f32=None):
         """frame_bgr: uint8 CUDA tensor H x W x 3.  Returns the uint8 BGR result (asynchronous on torch's current stream)."""
         import torch
-        if not self._layers:
+        if not self._loaded:
             raise FramewrightHipError(_lib.FW_ERR_INVALID, "SRVGGNetEngine: no weights loaded")
         t = frame_bgr
         if t.dtype != torch.uint8 or not t.is_cuda or t.dim() != 3 or t.shape[2] != 3 or not t.is_contiguous():
             raise ValueError("upscale_device expects a contiguous uint8 CUDA tensor H x W x 3")
-        lib, dev, s = self._lib, t.device, self.scale
+        if t.device != self._dev:
+            raise ValueError(f"tensor is on {t.device}, engine on {self._dev}")
+        s = self.scale
         H, W = int(t.shape[0]), int(t.shape[1])
         if out is None:
-            out = torch.empty((H * s, W * s, 3), dtype=torch.uint8, device=dev)
-        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            out = torch.empty((H * s, W * s, 3), dtype=torch.uint8, device=self._dev)
+        for x, dt in ((out, torch.uint8), (out_rgb_f32, torch.float32)):
+            if x is not None and (x.dtype != dt or tuple(x.shape) != (H * s, W * s, 3) or not x.is_contiguous() or x.device != self._dev):
+                raise ValueError("output tensor has the wrong dtype/shape/device")
         p = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
-        PL = H * W * 32                                        # elements per 32-channel plane
-        x0 = torch.empty((H, W, 32), dtype=self._tdt, device=dev)
-        _lib.check(lib.fw_u8_to_nhwc(self._dt, p(t), H, W, p(x0), 32, st))
-        bufs = [torch.empty((2, H, W, 32), dtype=self._tdt, device=dev) for _ in range(2)]   # chunk-planar, ping-pong
-        last = torch.empty((H, W, 64), dtype=torch.float32, device=dev)
-        cur = x0
-        for i, (wp, b, slopes, chunks) in enumerate(self._layers):
-            final = i == len(self._layers) - 1
-            dst = None if final else bufs[i & 1]
-            _lib.check(lib.fw_conv3x3_nhwc_ex(
-                self._dt, p(cur), 32, PL if chunks > 1 else 0, chunks, H, W, p(wp), p(b), 2, 0 if final else 2, 0,
-                None, 1.0, None, 1.0, p(slopes), 0, 0, 0, p(dst), 32, PL, 0, p(last) if final else None, st))
-            cur = dst
-        _lib.check(lib.fw_pixel_shuffle_add_u8(p(last), 64, p(t), H, W, s, p(out), p(out_rgb_f32), st))
+        st = C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)
+        _lib.check(self._lib.fw_srvgg_upscale_u8(self._h, p(t), _lib.FW_DEVICE, H, W, p(out), _lib.FW_DEVICE, p(out_rgb_f32), st))
         return out
 
     def upscale(self, frame_bgr: np.ndarray) -> np.ndarray:
@@ -170,4 +145,7 @@ class SRVGGNetEngine:
         return out.cpu().numpy()
 
     def close(self) -> None:
-        self._layers = []
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.fw_srvgg_destroy(h)
+        self._loaded = False
