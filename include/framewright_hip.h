@@ -238,6 +238,10 @@ int fw_grain_addback_u8(const uint8_t* original, const uint8_t* denoised, int he
  * synchronises `stream` before it returns. */
 int fw_resize_lanczos4_u8(const uint8_t* src, int src_h, int src_w, int channels, uint8_t* dst, int dst_h, int dst_w,
                           void* stream);
+/* The same on 16-bit images: RealESRGANer.enhance with outscale != netscale on a 16-bit frame (cv2.resize of a ushort image runs
+ * OpenCV's float path: float weights, eight products summed left to right per pass, saturate_cast<ushort>(cvRound)). */
+int fw_resize_lanczos4_u16(const uint16_t* src, int src_h, int src_w, int channels, uint16_t* dst, int dst_h, int dst_w,
+                           void* stream);
 
 /* -------------------------------------------------------------------------------------------------
  * Restormer building blocks (the reference's DEFAULT TAP model)
@@ -396,6 +400,9 @@ int fw_srvgg_set_tensor(fw_srvgg* net, const char* key, const float* data, size_
 int fw_srvgg_finalize(fw_srvgg* net);
 int fw_srvgg_upscale_u8(fw_srvgg* net, const uint8_t* in_bgr, int in_loc, int height, int width, uint8_t* out_bgr, int out_loc,
                         float* out_rgb_f32, void* stream);
+/* 16-bit frames (RealESRGANer.enhance: max_range 65535): uint16 BGR in, / 65535; uint16 BGR out, x 65535, round. */
+int fw_srvgg_upscale_u16(fw_srvgg* net, const uint16_t* in_bgr, int in_loc, int height, int width, uint16_t* out_bgr, int out_loc,
+                         float* out_rgb_f32, void* stream);
 size_t fw_srvgg_workspace_bytes(const fw_srvgg* net, int height, int width);
 double fw_srvgg_flops(const fw_srvgg* net, int height, int width);
 int fw_srvgg_destroy(fw_srvgg* net);

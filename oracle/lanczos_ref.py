@@ -7,6 +7,11 @@ its published algorithm (imgproc/resize.cpp: ``interpolateLanczos4``, ``resizeGe
 ``HResizeLanczos4<uchar,int,short>`` / ``VResizeLanczos4<uchar,int,short,FixedPtCast<int,uchar,22>>``) as the two separate
 passes OpenCV runs — **parity unpinned** (no cv2 to check against).  Known-answer properties are tested instead: identity
 at equal size, constants stay constant, exact 2:1 phase weights.
+
+``resize_lanczos4_u16`` is the same resize on 16-bit images (the tail of ``RealESRGANer.enhance`` on a 16-bit frame): OpenCV's
+path for ushort is float (``HResizeLanczos4<ushort,float,float>`` / ``VResizeLanczos4<ushort,float,float,Cast<float,ushort>>``):
+the normalised float weights, eight float32 products added left to right per pass, ``saturate_cast<ushort>(cvRound(sum))``.
+Also unpinned (and OpenCV's SIMD build may associate the vertical sum differently).
 """
 from __future__ import annotations
 
@@ -65,4 +70,36 @@ def resize_lanczos4_u8(img: np.ndarray, dw: int, dh: int) -> np.ndarray:
         ys = np.clip(yofs + k - 3, 0, hs - 1)
         out += hbuf[ys] * ib[:, k][:, None, None]
     out = np.clip((out + (1 << 21)) >> 22, 0, 255).astype(np.uint8)
+    return out[:, :, 0] if squeeze else out
+
+
+def float_tables(ssize: int, dsize: int):
+    scale = 1.0 / (dsize / ssize)
+    ofs = np.zeros(dsize, np.int64)
+    coef = np.zeros((dsize, 8), np.float32)
+    for d in range(dsize):
+        f = np.float32((d + 0.5) * scale - 0.5)
+        s0 = math.floor(float(f))
+        ofs[d] = s0
+        coef[d] = interpolate_lanczos4(np.float32(f - np.float32(s0)))
+    return ofs, coef
+
+
+def resize_lanczos4_u16(img: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    squeeze = img.ndim == 2
+    src = (img[:, :, None] if squeeze else img).astype(np.float32)
+    hs, ws, _ = src.shape
+    xofs, fa = float_tables(ws, dw)
+    yofs, fb = float_tables(hs, dh)
+    hbuf = None
+    for j in range(8):                                   # float32 throughout, left to right, each product rounded before the add
+        xs = np.clip(xofs + j - 3, 0, ws - 1)
+        term = (src[:, xs, :] * fa[:, j][None, :, None]).astype(np.float32)
+        hbuf = term if hbuf is None else (hbuf + term).astype(np.float32)
+    out = None
+    for k in range(8):
+        ys = np.clip(yofs + k - 3, 0, hs - 1)
+        term = (hbuf[ys] * fb[:, k][:, None, None]).astype(np.float32)
+        out = term if out is None else (out + term).astype(np.float32)
+    out = np.clip(np.rint(out), 0, 65535).astype(np.uint16)  # cvRound: half to even
     return out[:, :, 0] if squeeze else out

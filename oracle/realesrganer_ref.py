@@ -117,10 +117,8 @@ def enhance(model: Model, img: np.ndarray, scale: int, outscale: Optional[float]
         res = (out_img * 255.0).round().astype(np.uint8)
     if outscale is not None and float(outscale) != float(scale):
         # cv2.resize(output, (int(w_input * outscale), int(h_input * outscale)), interpolation=cv2.INTER_LANCZOS4)
-        if res.dtype != np.uint8:
-            raise NotImplementedError("Lanczos resize of 16-bit output is not restated")
-        from .lanczos_ref import resize_lanczos4_u8
-        res = resize_lanczos4_u8(res, int(w_input * outscale), int(h_input * outscale))
+        from .lanczos_ref import resize_lanczos4_u16, resize_lanczos4_u8
+        res = (resize_lanczos4_u8 if res.dtype == np.uint8 else resize_lanczos4_u16)(res, int(w_input * outscale), int(h_input * outscale))
     return res, img_mode
 
 

@@ -45,6 +45,28 @@ def test_srvgg_vs_oracle(hip_lib, dtype, max_abs, min_psnr, model, H, W):
     assert want.std() > 0.05  # the synthetic net is not degenerate
 
 
+def test_srvgg_16_bit_frame_through_the_engine_and_the_upsampler(hip_lib):
+    """A 16-bit frame (RealESRGANer.enhance: max_range 65535) on an SRVGG checkpoint: uint16 in, uint16 out, the same network on
+    input / 65535; equal to the fp32 oracle within the f16 bar, and what HipRealESRGANer.enhance returns for it."""
+    from framewright_amd.realesrgan import HipRealESRGANer
+    num_conv, scale = S.SRVGG_MODELS["realesr-animevideov3"]
+    sd = S.synthetic_srvgg_state(num_conv, scale, seed=3)
+    f8 = synthetic_frames(1, 24, 40, seed=8)[0]
+    f16 = f8.astype(np.uint16) * 257 + 13                                         # not a multiple of 257: real 16-bit content
+    eng = S.SRVGGNetEngine(num_conv, scale, "f16")
+    eng.load_state_dict(sd)
+    got = eng.upscale(f16)
+    assert got.dtype == np.uint16 and got.shape == (24 * scale, 40 * scale, 3)
+    x = torch.from_numpy(f16[:, :, ::-1].astype(np.float32) / 65535.0).permute(2, 0, 1).unsqueeze(0)
+    with torch.no_grad():
+        want = ref.srvgg_forward({k: torch.from_numpy(v) for k, v in sd.items()}, x, num_conv, scale).squeeze(0).permute(1, 2, 0).numpy()
+    want16 = np.rint(np.clip(want, 0, 1) * 65535.0).astype(np.int64)[:, :, ::-1]
+    assert np.abs(got.astype(np.int64) - want16).max() <= 66                      # 1e-3 of the range
+    out, mode = HipRealESRGANer(scale, eng).enhance(f16)
+    assert mode == "RGB" and np.array_equal(out, got)
+    eng.close()
+
+
 def test_srvgg_rejects_wrong_state(hip_lib):
     eng = S.SRVGGNetEngine(16, 4, "bf16")
     sd = S.synthetic_srvgg_state(16, 4)

@@ -32,7 +32,7 @@ EXPORTS = [
     "fw_depth_to_space4_f32", "fw_ifnet_accumulate", "fw_ifnet_blend", "fw_unsharp_mask_u8",
     "fw_ifnet_create", "fw_ifnet_set_tensor", "fw_ifnet_finalize", "fw_ifnet_interp_u8", "fw_ifnet_workspace_bytes", "fw_ifnet_flops",
     "fw_ifnet_destroy",
-    "fw_srvgg_create", "fw_srvgg_set_tensor", "fw_srvgg_finalize", "fw_srvgg_upscale_u8", "fw_srvgg_workspace_bytes", "fw_srvgg_flops",
+    "fw_srvgg_create", "fw_srvgg_set_tensor", "fw_srvgg_finalize", "fw_srvgg_upscale_u8", "fw_srvgg_upscale_u16", "fw_resize_lanczos4_u16", "fw_srvgg_workspace_bytes", "fw_srvgg_flops",
     "fw_srvgg_destroy",
     "fw_restormer_create", "fw_restormer_set_tensor", "fw_restormer_finalize", "fw_restormer_denoise_u8",
     "fw_restormer_workspace_bytes", "fw_restormer_destroy", "fw_preserve_edges_scratch_bytes", "fw_preserve_edges_u8",
@@ -153,6 +153,10 @@ def _declare_ifnet(lib: C.CDLL) -> None:
     lib.fw_srvgg_finalize.argtypes = [vp]
     lib.fw_srvgg_upscale_u8.restype = i32
     lib.fw_srvgg_upscale_u8.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp]
+    lib.fw_srvgg_upscale_u16.restype = i32
+    lib.fw_srvgg_upscale_u16.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp]
+    lib.fw_resize_lanczos4_u16.restype = i32
+    lib.fw_resize_lanczos4_u16.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp]
     lib.fw_srvgg_workspace_bytes.restype = sz
     lib.fw_srvgg_workspace_bytes.argtypes = [vp, i32, i32]
     lib.fw_srvgg_flops.restype = C.c_double

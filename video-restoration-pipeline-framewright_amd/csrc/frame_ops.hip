@@ -185,19 +185,22 @@ void launch_flow_accumulate_finish(const double* acc, const double* wsum, long n
 
 // ---- SRVGGNetCompact tail (Real-ESRGAN realesr-animevideov3 / realesr-general-x4v3; reference model table
 //      src/framewright/processors/pytorch_realesrgan.py:119-128 declares them, the network itself is third-party) ---------
+// S = uint8_t (range 255) or uint16_t (range 65535: RealESRGANer.enhance normalises a 16-bit image by 65535 and returns uint16)
+template <typename S>
 __global__ __launch_bounds__(256) void pixel_shuffle_add_kernel(const float* __restrict__ conv, int cstride,
-                                                                const uint8_t* __restrict__ in_bgr, int H, int W, int s,
-                                                                uint8_t* out_bgr, float* out_rgb) {
+                                                                const S* __restrict__ in_bgr, int H, int W, int s,
+                                                                S* out_bgr, float* out_rgb) {
+    constexpr float TOP = sizeof(S) == 1 ? 255.0f : 65535.0f;
     const int Wo = W * s;
     const long n = (long)H * s * Wo;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int Y = (int)(i / Wo), X = (int)(i - (long)Y * Wo);
         const int y = Y / s, x = X / s, sub = (Y - y * s) * s + (X - x * s);
         const float* c = conv + ((size_t)y * W + x) * cstride;
-        const uint8_t* px = in_bgr + ((size_t)y * W + x) * 3;
+        const S* px = in_bgr + ((size_t)y * W + x) * 3;
         float v[3];
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) v[ch] = c[ch * s * s + sub] + px[2 - ch] / 255.0f;
+        for (int ch = 0; ch < 3; ++ch) v[ch] = c[ch * s * s + sub] + px[2 - ch] / TOP;
         if (out_rgb) {
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) out_rgb[(size_t)i * 3 + ch] = v[ch];
@@ -205,19 +208,29 @@ __global__ __launch_bounds__(256) void pixel_shuffle_add_kernel(const float* __r
         if (out_bgr) {
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch)
-                out_bgr[(size_t)i * 3 + 2 - ch] = (uint8_t)rintf(fminf(fmaxf(v[ch], 0.f), 1.f) * 255.f);
+                out_bgr[(size_t)i * 3 + 2 - ch] = (S)rintf(fminf(fmaxf(v[ch], 0.f), 1.f) * TOP);
         }
     }
 }
 
-void launch_pixel_shuffle_add(const float* conv, int cstride, const uint8_t* in_bgr, int H, int W, int scale, uint8_t* out_bgr,
-                              float* out_rgb, hipStream_t st) {
+void launch_pixel_shuffle_add_bits(const float* conv, int cstride, const void* in_bgr, int bits, int H, int W, int scale, void* out_bgr,
+                                   float* out_rgb, hipStream_t st) {
     if (scale < 1 || scale > 4 || cstride < 3 * scale * scale) throw Error(1, "pixel_shuffle_add: bad scale / channel stride");
+    if (bits != 8 && bits != 16) throw Error(1, "pixel_shuffle_add: 8- or 16-bit samples expected");
     const long n = (long)H * scale * W * scale;
     const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    hipLaunchKernelGGL(pixel_shuffle_add_kernel, dim3(blocks), dim3(256), 0, st, conv, cstride, in_bgr, H, W, scale, out_bgr,
-                       out_rgb);
+    if (bits == 8)
+        hipLaunchKernelGGL((pixel_shuffle_add_kernel<uint8_t>), dim3(blocks), dim3(256), 0, st, conv, cstride, (const uint8_t*)in_bgr, H, W, scale,
+                           (uint8_t*)out_bgr, out_rgb);
+    else
+        hipLaunchKernelGGL((pixel_shuffle_add_kernel<uint16_t>), dim3(blocks), dim3(256), 0, st, conv, cstride, (const uint16_t*)in_bgr, H, W, scale,
+                           (uint16_t*)out_bgr, out_rgb);
     FW_HIP_CHECK(hipGetLastError());
+}
+
+void launch_pixel_shuffle_add(const float* conv, int cstride, const uint8_t* in_bgr, int H, int W, int scale, uint8_t* out_bgr,
+                              float* out_rgb, hipStream_t st) {
+    launch_pixel_shuffle_add_bits(conv, cstride, in_bgr, 8, H, W, scale, out_bgr, out_rgb, st);
 }
 
 // ---- TAP (NAFNet) frame path ---------------------------------------------------------------------------------
@@ -511,6 +524,88 @@ void launch_resize_lanczos4_u8(const uint8_t* src, int Hs, int Ws, int C, uint8_
     // the tables live in pageable host memory and a per-call device block: finish before both go away (this is the
     // once-per-frame tail of a non-default configuration, not the hot path)
     const hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    FW_HIP_CHECK(e);
+    FW_HIP_CHECK(e2);
+}
+
+// The same resize on 16-bit images (RealESRGANer.enhance with outscale != netscale on a 16-bit frame).  OpenCV's path for ushort is
+// float: HResizeLanczos4<ushort, float, float> then VResizeLanczos4<ushort, float, float, Cast<float, ushort>> - the normalised
+// float weights themselves, eight products summed left to right per pass, saturate_cast<ushort>(cvRound(sum)).  This file is
+// compiled with -ffp-contract=off, so a * b + c rounds twice like the scalar C++ does.  (OpenCV's SIMD build may associate the
+// vertical sum differently; without cv2 in the image the restatement is unpinned either way - oracle/lanczos_ref.py.)
+__global__ __launch_bounds__(256) void resize_lanczos4_u16_kernel(const uint16_t* __restrict__ src, int Hs, int Ws, int C,
+                                                                  uint16_t* __restrict__ dst, int Hd, int Wd,
+                                                                  const int* __restrict__ xofs, const float* __restrict__ alpha,
+                                                                  const int* __restrict__ yofs, const float* __restrict__ beta) {
+    const long total = (long)Hd * Wd;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int dy = (int)(i / Wd), dx = (int)(i - (long)dy * Wd);
+        const int sx = xofs[dx], sy = yofs[dy];
+        int xs[8];
+        float a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int x = sx + j - 3;
+            x = x < 0 ? 0 : (x >= Ws ? Ws - 1 : x);
+            xs[j] = x * C;
+            a[j] = alpha[dx * 8 + j];
+            b[j] = beta[dy * 8 + j];
+        }
+        for (int c = 0; c < C; ++c) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int y = sy + k - 3;
+                y = y < 0 ? 0 : (y >= Hs ? Hs - 1 : y);
+                const uint16_t* row = src + (long)y * Ws * C + c;
+                float h = (float)row[xs[0]] * a[0];
+#pragma unroll
+                for (int j = 1; j < 8; ++j) h = h + (float)row[xs[j]] * a[j];
+                v = k == 0 ? h * b[0] : v + h * b[k];
+            }
+            const float r = rintf(v);   // cvRound: round half to even
+            dst[i * C + c] = (uint16_t)(r < 0.f ? 0.f : (r > 65535.f ? 65535.f : r));
+        }
+    }
+}
+
+void launch_resize_lanczos4_u16(const uint16_t* src, int Hs, int Ws, int C, uint16_t* dst, int Hd, int Wd, hipStream_t st) {
+    auto tables = [](int ssize, int dsize, std::vector<int>& ofs, std::vector<float>& coef) {
+        const double inv_scale = (double)dsize / ssize, scale = 1. / inv_scale;
+        ofs.resize(dsize);
+        coef.resize((size_t)dsize * 8);
+        for (int d = 0; d < dsize; ++d) {
+            float f = (float)((d + 0.5) * scale - 0.5);
+            const int s0 = (int)std::floor(f);
+            f -= s0;
+            ofs[d] = s0;
+            lanczos4_coeffs(f, coef.data() + (size_t)d * 8);
+        }
+    };
+    std::vector<int> xofs, yofs;
+    std::vector<float> fa, fb;
+    tables(Ws, Wd, xofs, fa);
+    tables(Hs, Hd, yofs, fb);
+    const size_t nx = (size_t)Wd, ny = (size_t)Hd;
+    const size_t bytes = (nx + ny) * 4 + (nx + ny) * 32;   // [xofs | yofs | alpha | beta]
+    char* d = nullptr;
+    FW_HIP_CHECK(hipMalloc((void**)&d, bytes));
+    std::vector<char> h(bytes);
+    memcpy(h.data(), xofs.data(), nx * 4);
+    memcpy(h.data() + nx * 4, yofs.data(), ny * 4);
+    memcpy(h.data() + (nx + ny) * 4, fa.data(), nx * 32);
+    memcpy(h.data() + (nx + ny) * 4 + nx * 32, fb.data(), ny * 32);
+    hipError_t e = hipMemcpyAsync(d, h.data(), bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        const long total = (long)Hd * Wd;
+        const int blocks = (int)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
+        hipLaunchKernelGGL(resize_lanczos4_u16_kernel, dim3(blocks), dim3(256), 0, st, src, Hs, Ws, C, dst, Hd, Wd,
+                           reinterpret_cast<const int*>(d), reinterpret_cast<const float*>(d + (nx + ny) * 4),
+                           reinterpret_cast<const int*>(d + nx * 4), reinterpret_cast<const float*>(d + (nx + ny) * 4 + nx * 32));
+        e = hipGetLastError();
+    }
+    const hipError_t e2 = hipStreamSynchronize(st);   // tables in pageable host memory and a per-call device block (as for 8-bit)
     (void)hipFree(d);
     FW_HIP_CHECK(e);
     FW_HIP_CHECK(e2);

@@ -119,6 +119,9 @@ void launch_frame_to_nhwc(DType dt, const void* in_bgr, int bits, int H, int W, 
 // the nearest-upsampled input, -> RGB float and/or clamp -> x255 -> rint -> uint8 BGR, both [scale*H][scale*W][3].
 void launch_pixel_shuffle_add(const float* conv, int cstride, const uint8_t* in_bgr, int H, int W, int scale, uint8_t* out_bgr,
                               float* out_rgb, hipStream_t stream);
+// the same for 8- or 16-bit samples (bits; 16: uint16 BGR base and output, /65535 and x65535)
+void launch_pixel_shuffle_add_bits(const float* conv, int cstride, const void* in_bgr, int bits, int H, int W, int scale, void* out_bgr,
+                                   float* out_rgb, hipStream_t stream);
 
 // ---- NAFNet building blocks (nn_ops.hip) -------------------------------------------------------------
 enum PointwiseMode : int {
@@ -247,6 +250,8 @@ void launch_grain_addback(const uint8_t* orig, const uint8_t* den, int H, int W,
                           hipStream_t st);
 // cv2.resize(INTER_LANCZOS4) on 8-bit H x W x C images (device pointers); synchronises the stream
 void launch_resize_lanczos4_u8(const uint8_t* src, int Hs, int Ws, int C, uint8_t* dst, int Hd, int Wd, hipStream_t st);
+// the same on 16-bit images (OpenCV's float path for ushort); synchronises the stream
+void launch_resize_lanczos4_u16(const uint16_t* src, int Hs, int Ws, int C, uint16_t* dst, int Hd, int Wd, hipStream_t st);
 void launch_flow_accumulate_finish(const double* acc, const double* wsum, long n, uint8_t* out, hipStream_t st);
 // `_preserve_edges` (temporal_denoise.py:1636-1667): Canny edge mask of `orig` blends it over `den`; synchronises the stream
 size_t preserve_edges_scratch_bytes(int H, int W);

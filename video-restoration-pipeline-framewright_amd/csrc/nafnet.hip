@@ -678,6 +678,12 @@ int fw_resize_lanczos4_u8(const uint8_t* src, int src_h, int src_w, int channels
     return guarded([&] { launch_resize_lanczos4_u8(src, src_h, src_w, channels, dst, dst_h, dst_w, (hipStream_t)stream); });
 }
 
+int fw_resize_lanczos4_u16(const uint16_t* src, int src_h, int src_w, int channels, uint16_t* dst, int dst_h, int dst_w, void* stream) {
+    if (!src || !dst || src_h < 1 || src_w < 1 || dst_h < 1 || dst_w < 1 || channels < 1 || channels > 4)
+        return fail(FW_ERR_INVALID, "fw_resize_lanczos4_u16: bad argument");
+    return guarded([&] { launch_resize_lanczos4_u16(src, src_h, src_w, channels, dst, dst_h, dst_w, (hipStream_t)stream); });
+}
+
 int fw_nafnet_destroy(fw_nafnet* n) {
     if (!n) return FW_OK;
     { std::lock_guard<std::mutex> lk(n->mu); }   // a call in flight on another thread finishes first

@@ -98,8 +98,8 @@ Plan make_plan(const fw_srvgg* n, int H, int W) {
     const size_t M = (size_t)H * W;
     size_t o = 0;
     auto take = [&](size_t b) { size_t at = o; o += up256(b); return at; };
-    p.in_u8 = take(M * 3);
-    p.out_u8 = take(M * n->scale * n->scale * 3);
+    p.in_u8 = take(M * 3 * 2);                               // staging for host buffers, 8- or 16-bit samples
+    p.out_u8 = take(M * n->scale * n->scale * 3 * 2);
     p.x0 = take(M * 32 * 2);
     p.buf0 = take(M * 64 * 2);
     p.buf1 = take(M * 64 * 2);
@@ -108,11 +108,11 @@ Plan make_plan(const fw_srvgg* n, int H, int W) {
     return p;
 }
 
-void forward(fw_srvgg* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, float* d_rgb, hipStream_t st) {
+void forward(fw_srvgg* n, const void* d_in, int bits, int H, int W, void* d_out, float* d_rgb, hipStream_t st) {
     const Plan pl = make_plan(n, H, W);
     char* ws = (char*)n->ws.p;
     const long PL = (long)H * W * 32;    // elements per 32-channel plane
-    launch_u8_to_nhwc(n->dt, d_in, H, W, ws + pl.x0, 32, 1, st);
+    launch_frame_to_nhwc(n->dt, d_in, bits, H, W, ws + pl.x0, 32, 1, st);
     const void* cur = ws + pl.x0;
     for (size_t i = 0; i < n->layers.size(); ++i) {
         const Layer& L = n->layers[i];
@@ -137,7 +137,7 @@ void forward(fw_srvgg* n, const uint8_t* d_in, int H, int W, uint8_t* d_out, flo
         launch_conv3x3(n->dt, 2, EPI_STORE, p, st);
         cur = dst;
     }
-    launch_pixel_shuffle_add((const float*)(ws + pl.last), 64, d_in, H, W, n->scale, d_out, d_rgb, st);
+    launch_pixel_shuffle_add_bits((const float*)(ws + pl.last), 64, d_in, bits, H, W, n->scale, d_out, d_rgb, st);
 }
 
 }  // namespace
@@ -235,13 +235,14 @@ double fw_srvgg_flops(const fw_srvgg* n, int H, int W) {
     return 2.0 * mac * H * W;
 }
 
-int fw_srvgg_upscale_u8(fw_srvgg* n, const uint8_t* in_bgr, int in_loc, int H, int W, uint8_t* out_bgr, int out_loc, float* out_rgb_f32,
-                        void* stream) {
-    if (!n || !in_bgr) return fail(FW_ERR_INVALID, "fw_srvgg_upscale_u8: NULL argument");
-    if (!out_bgr && !out_rgb_f32) return fail(FW_ERR_INVALID, "fw_srvgg_upscale_u8: no output requested");
-    if (H < 1 || W < 1 || H > 16384 || W > 16384) return fail(FW_ERR_INVALID, "fw_srvgg_upscale_u8: bad frame size");
+namespace {
+int upscale_any(fw_srvgg* n, const void* in_bgr, int bits, int in_loc, int H, int W, void* out_bgr, int out_loc, float* out_rgb_f32, void* stream,
+                const char* who) {
+    if (!n || !in_bgr) return fail(FW_ERR_INVALID, std::string(who) + ": NULL argument");
+    if (!out_bgr && !out_rgb_f32) return fail(FW_ERR_INVALID, std::string(who) + ": no output requested");
+    if (H < 1 || W < 1 || H > 16384 || W > 16384) return fail(FW_ERR_INVALID, std::string(who) + ": bad frame size");
     if ((in_loc != FW_HOST && in_loc != FW_DEVICE) || (out_loc != FW_HOST && out_loc != FW_DEVICE))
-        return fail(FW_ERR_INVALID, "fw_srvgg_upscale_u8: bad buffer location");
+        return fail(FW_ERR_INVALID, std::string(who) + ": bad buffer location");
     int rc = fw_srvgg_finalize(n);
     if (rc != FW_OK) return rc;
     return guarded([&] {
@@ -256,20 +257,31 @@ int fw_srvgg_upscale_u8(fw_srvgg* n, const uint8_t* in_bgr, int in_loc, int H, i
             n->ws.bytes = pl.total;
         }
         char* ws = (char*)n->ws.p;
-        const size_t in_bytes = (size_t)H * W * 3, out_bytes = in_bytes * n->scale * n->scale;
-        const uint8_t* d_in = in_bgr;
+        const size_t in_bytes = (size_t)H * W * 3 * (bits / 8), out_bytes = in_bytes * n->scale * n->scale;
+        const void* d_in = in_bgr;
         if (in_loc == FW_HOST) {
             FW_HIP_CHECK(hipMemcpyAsync(ws + pl.in_u8, in_bgr, in_bytes, hipMemcpyHostToDevice, st));
-            d_in = (const uint8_t*)(ws + pl.in_u8);
+            d_in = ws + pl.in_u8;
         }
-        uint8_t* d_out = out_bgr;
-        if (out_bgr && out_loc == FW_HOST) d_out = (uint8_t*)(ws + pl.out_u8);
-        forward(n, d_in, H, W, d_out, out_rgb_f32, st);
+        void* d_out = out_bgr;
+        if (out_bgr && out_loc == FW_HOST) d_out = ws + pl.out_u8;
+        forward(n, d_in, bits, H, W, d_out, out_rgb_f32, st);
         if (out_bgr && out_loc == FW_HOST) {
             FW_HIP_CHECK(hipMemcpyAsync(out_bgr, d_out, out_bytes, hipMemcpyDeviceToHost, st));
             FW_HIP_CHECK(hipStreamSynchronize(st));
         }
     });
+}
+}  // namespace
+
+int fw_srvgg_upscale_u8(fw_srvgg* n, const uint8_t* in_bgr, int in_loc, int H, int W, uint8_t* out_bgr, int out_loc, float* out_rgb_f32,
+                        void* stream) {
+    return upscale_any(n, in_bgr, 8, in_loc, H, W, out_bgr, out_loc, out_rgb_f32, stream, "fw_srvgg_upscale_u8");
+}
+
+int fw_srvgg_upscale_u16(fw_srvgg* n, const uint16_t* in_bgr, int in_loc, int H, int W, uint16_t* out_bgr, int out_loc, float* out_rgb_f32,
+                         void* stream) {
+    return upscale_any(n, in_bgr, 16, in_loc, H, W, out_bgr, out_loc, out_rgb_f32, stream, "fw_srvgg_upscale_u16");
 }
 
 int fw_srvgg_destroy(fw_srvgg* n) {

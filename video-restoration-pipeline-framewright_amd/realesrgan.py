@@ -270,19 +270,23 @@ def _check_frame(frame: np.ndarray) -> np.ndarray:
 
 
 def resize_lanczos4_u8(img: np.ndarray, dst_w: int, dst_h: int, device_id: int = 0) -> np.ndarray:
-    """``cv2.resize(img, (dst_w, dst_h), interpolation=cv2.INTER_LANCZOS4)`` for an 8-bit H x W [x C] array, on the GPU
-    (fw_resize_lanczos4_u8: OpenCV's fixed-point arithmetic; oracle/lanczos_ref.py is the CPU restatement)."""
+    """``cv2.resize(img, (dst_w, dst_h), interpolation=cv2.INTER_LANCZOS4)`` for an 8-bit or 16-bit H x W [x C] array, on the GPU
+    (fw_resize_lanczos4_u8: OpenCV's fixed-point arithmetic for uchar; fw_resize_lanczos4_u16: its float path for ushort;
+    oracle/lanczos_ref.py holds the CPU restatements)."""
     import torch
-    if img.dtype != np.uint8 or img.ndim not in (2, 3) or dst_w < 1 or dst_h < 1:
-        raise ValueError("resize_lanczos4_u8: uint8 H x W [x C] image and a positive size expected")
+    if img.dtype not in (np.uint8, np.uint16) or img.ndim not in (2, 3) or dst_w < 1 or dst_h < 1:
+        raise ValueError("resize_lanczos4_u8: uint8 / uint16 H x W [x C] image and a positive size expected")
     c = 1 if img.ndim == 2 else img.shape[2]
+    wide = img.dtype == np.uint16
     with torch.cuda.device(device_id):
-        src = torch.from_numpy(np.ascontiguousarray(img)).cuda()
-        dst = torch.empty((dst_h, dst_w) if img.ndim == 2 else (dst_h, dst_w, c), dtype=torch.uint8, device="cuda")
+        a = np.ascontiguousarray(img)
+        src = torch.from_numpy(a.view(np.int16) if wide else a).cuda()          # the bytes only: torch's uint16 support is partial
+        dst = torch.empty((dst_h, dst_w) if img.ndim == 2 else (dst_h, dst_w, c), dtype=torch.int16 if wide else torch.uint8, device="cuda")
         st = torch.cuda.current_stream().cuda_stream
-        _lib.check(_lib.load().fw_resize_lanczos4_u8(C.c_void_p(src.data_ptr()), img.shape[0], img.shape[1], c,
-                                                     C.c_void_p(dst.data_ptr()), dst_h, dst_w, C.c_void_p(st)))
-        return dst.cpu().numpy()
+        fn = _lib.load().fw_resize_lanczos4_u16 if wide else _lib.load().fw_resize_lanczos4_u8
+        _lib.check(fn(C.c_void_p(src.data_ptr()), img.shape[0], img.shape[1], c, C.c_void_p(dst.data_ptr()), dst_h, dst_w, C.c_void_p(st)))
+        out = dst.cpu().numpy()
+        return out.view(np.uint16) if wide else out
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -331,10 +335,7 @@ class HipRealESRGANer:
             # on the quantised output, whatever its channel count (reached with scale_factor 2 and a x4 model,
             # pytorch_realesrgan.py:223)
             h_in, w_in = img.shape[:2]
-            if out.dtype != np.uint8:
-                raise NotImplementedError("outscale != netscale on a 16-bit frame: OpenCV's float Lanczos path for ushort "
-                                          "images is not restated")
-            out = resize_lanczos4_u8(out, int(w_in * outscale), int(h_in * outscale), self.engine.device_id)
+            out = resize_lanczos4_u8(out, int(w_in * outscale), int(h_in * outscale), self.engine.device_id)   # uint8 or uint16
         return out, mode
 
     def _enhance_netscale(self, img: np.ndarray):
@@ -343,8 +344,6 @@ class HipRealESRGANer:
         # 16-bit PNG) is normalised by 65535 and comes back as uint16; anything else is 8-bit
         sixteen = img.size > 0 and float(np.max(img)) > 256
         if sixteen:
-            if not isinstance(self.engine, RRDBNetEngine):
-                raise NotImplementedError("16-bit frames are supported on the RRDBNet engines only (fw_rrdbnet_upscale_u16)")
             img = img if img.dtype == np.uint16 else np.clip(np.rint(img), 0, 65535).astype(np.uint16)
             top = 65535
         else:

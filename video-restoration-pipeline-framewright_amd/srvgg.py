@@ -137,6 +137,18 @@ class SRVGGNetEngine:
     def upscale(self, frame_bgr: np.ndarray) -> np.ndarray:
         """H x W x 3 uint8 BGR (host) -> sH x sW x 3 uint8 BGR (host)."""
         import torch
+        if isinstance(frame_bgr, np.ndarray) and frame_bgr.dtype == np.uint16:
+            # a 16-bit frame (range 65535) comes back as uint16, as RealESRGANer.enhance returns it
+            if frame_bgr.ndim != 3 or frame_bgr.shape[2] != 3:
+                raise ValueError("expected an H x W x 3 uint16 BGR frame")
+            if not self._loaded:
+                raise FramewrightHipError(_lib.FW_ERR_INVALID, "SRVGGNetEngine: no weights loaded")
+            f16 = np.ascontiguousarray(frame_bgr)
+            h, w = f16.shape[:2]
+            out16 = np.empty((h * self.scale, w * self.scale, 3), dtype=np.uint16)
+            _lib.check(self._lib.fw_srvgg_upscale_u16(self._h, C.c_void_p(f16.ctypes.data), _lib.FW_HOST, h, w, C.c_void_p(out16.ctypes.data),
+                                                      _lib.FW_HOST, None, None))
+            return out16
         if not isinstance(frame_bgr, np.ndarray) or frame_bgr.dtype != np.uint8 or frame_bgr.ndim != 3 or frame_bgr.shape[2] != 3:
             raise ValueError("expected an H x W x 3 uint8 BGR frame")
         with torch.cuda.device(self._dev):
