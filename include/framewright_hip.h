@@ -388,6 +388,20 @@ int fw_ifnet_blend(const float* img0, const float* img1, const float* flow, cons
 int fw_unsharp_mask_u8(const uint8_t* src, int height, int width, int channels, int box_radius, unsigned ww, unsigned fw_weight,
                        int passes, int percent, int threshold, uint8_t* scratch_a, uint8_t* scratch_b, uint8_t* out, void* stream);
 
+/* ---- AESRGAN (RRDB trunk + self-attention blocks) as one engine (csrc/aesrgan.hip) -------------------------------------------------
+ * The reference's in-tree network of AESRGANFaceRestorer (processors/aesrgan_face.py:205-269, AttentionBlock :142-168): create,
+ * hand over the tensors (BasicSR's names for the trunk / tail: conv_first, body.{i}.rdb{1,2,3}.conv{1..5}, conv_body, conv_up1
+ * [, conv_up2], conv_hr, conv_last with .weight / .bias; attn.{i}.query|key|value.weight / .bias and attn.{i}.gamma for the block
+ * behind RRDB i), finalize, then fw_aesrgan_forward_rgb on fp32 RGB crops in [0, 1] on the device: what AESRGAN.forward returns for
+ * a 1 x 3 x H x W input (NHWC, un-clamped).  The attention matrix is pixels x pixels: crops of up to 512 x 512. */
+typedef struct fw_aesrgan fw_aesrgan;
+int fw_aesrgan_create(int device_id, int num_block, int scale, int num_attention, int dtype, fw_aesrgan** out);
+int fw_aesrgan_set_tensor(fw_aesrgan* net, const char* key, const float* data, size_t numel);
+int fw_aesrgan_finalize(fw_aesrgan* net);
+int fw_aesrgan_forward_rgb(fw_aesrgan* net, const float* x_rgb, int height, int width, float* out_rgb, void* stream);
+size_t fw_aesrgan_workspace_bytes(fw_aesrgan* net, int height, int width);
+int fw_aesrgan_destroy(fw_aesrgan* net);
+
 /* ---- SRVGGNetCompact as one engine (csrc/srvgg.hip) ---------------------------------------------------------------------------
  * The network of the Real-ESRGAN checkpoints realesr-animevideov3 (num_conv 16) / realesr-general-x4v3 (num_conv 32), which the
  * reference lists in its model table (processors/pytorch_realesrgan.py:119-128): create, hand over the tensors of the published

@@ -32,6 +32,7 @@ EXPORTS = [
     "fw_depth_to_space4_f32", "fw_ifnet_accumulate", "fw_ifnet_blend", "fw_unsharp_mask_u8",
     "fw_ifnet_create", "fw_ifnet_set_tensor", "fw_ifnet_finalize", "fw_ifnet_interp_u8", "fw_ifnet_workspace_bytes", "fw_ifnet_flops",
     "fw_ifnet_destroy",
+    "fw_aesrgan_create", "fw_aesrgan_set_tensor", "fw_aesrgan_finalize", "fw_aesrgan_forward_rgb", "fw_aesrgan_workspace_bytes", "fw_aesrgan_destroy",
     "fw_srvgg_create", "fw_srvgg_set_tensor", "fw_srvgg_finalize", "fw_srvgg_upscale_u8", "fw_srvgg_upscale_u16", "fw_resize_lanczos4_u16", "fw_srvgg_workspace_bytes", "fw_srvgg_flops",
     "fw_srvgg_destroy",
     "fw_restormer_create", "fw_restormer_set_tensor", "fw_restormer_finalize", "fw_restormer_denoise_u8",
@@ -145,6 +146,18 @@ def _declare_ifnet(lib: C.CDLL) -> None:
     lib.fw_ifnet_accumulate.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp, i32, vp]
     lib.fw_ifnet_blend.restype = i32
     lib.fw_ifnet_blend.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
+    lib.fw_aesrgan_create.restype = i32
+    lib.fw_aesrgan_create.argtypes = [i32, i32, i32, i32, i32, C.POINTER(vp)]
+    lib.fw_aesrgan_set_tensor.restype = i32
+    lib.fw_aesrgan_set_tensor.argtypes = [vp, C.c_char_p, vp, sz]
+    lib.fw_aesrgan_finalize.restype = i32
+    lib.fw_aesrgan_finalize.argtypes = [vp]
+    lib.fw_aesrgan_forward_rgb.restype = i32
+    lib.fw_aesrgan_forward_rgb.argtypes = [vp, vp, i32, i32, vp, vp]
+    lib.fw_aesrgan_workspace_bytes.restype = sz
+    lib.fw_aesrgan_workspace_bytes.argtypes = [vp, i32, i32]
+    lib.fw_aesrgan_destroy.restype = i32
+    lib.fw_aesrgan_destroy.argtypes = [vp]
     lib.fw_srvgg_create.restype = i32
     lib.fw_srvgg_create.argtypes = [i32, i32, i32, i32, i32, C.POINTER(vp)]
     lib.fw_srvgg_set_tensor.restype = i32

@@ -233,6 +233,39 @@ void launch_pixel_shuffle_add(const float* conv, int cstride, const uint8_t* in_
     launch_pixel_shuffle_add_bits(conv, cstride, in_bgr, 8, H, W, scale, out_bgr, out_rgb, st);
 }
 
+// ---- AESRGAN (csrc/aesrgan.hip): fp32 RGB [M][3] <-> the conv kernels' layouts ----------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rgb_f32_to_nhwc_kernel(const float* __restrict__ x, long M, T* out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (long)gridDim.x * blockDim.x) {
+        float v[8] = {x[i * 3], x[i * 3 + 1], x[i * 3 + 2], 0, 0, 0, 0, 0};
+        uint4* o = reinterpret_cast<uint4*>(out + (size_t)i * 32);
+        o[0] = pack8<T>(v);
+        o[1] = make_uint4(0, 0, 0, 0);
+        o[2] = make_uint4(0, 0, 0, 0);
+        o[3] = make_uint4(0, 0, 0, 0);
+    }
+}
+void launch_rgb_f32_to_nhwc(DType dt, const float* x, long M, void* out, hipStream_t st) {
+    const int blocks = (int)((M + 255) / 256 < 2048 ? (M + 255) / 256 : 2048);
+    if (dt == DT_BF16)
+        hipLaunchKernelGGL((rgb_f32_to_nhwc_kernel<__bf16>), dim3(blocks), dim3(256), 0, st, x, M, (__bf16*)out);
+    else
+        hipLaunchKernelGGL((rgb_f32_to_nhwc_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, x, M, (_Float16*)out);
+    FW_HIP_CHECK(hipGetLastError());
+}
+__global__ __launch_bounds__(256) void take_rgb_f32_kernel(const float* __restrict__ src, int cstride, long M, float* out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < M * 3; i += (long)gridDim.x * blockDim.x) {
+        const long px = i / 3;
+        out[i] = src[px * cstride + (i - px * 3)];
+    }
+}
+void launch_take_rgb_f32(const float* src, int cstride, long M, float* out, hipStream_t st) {
+    const long n = M * 3;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(take_rgb_f32_kernel, dim3(blocks), dim3(256), 0, st, src, cstride, M, out);
+    FW_HIP_CHECK(hipGetLastError());
+}
+
 // ---- TAP (NAFNet) frame path ---------------------------------------------------------------------------------
 // uint8 BGR H x W x 3 -> typed [Hp][Wp][32] RGB/255 with zeros outside H x W (NAFNet.check_image_size zero pad,
 // SURVEY.md §A.3; pre-processing reference src/framewright/processors/tap_denoise.py:373-397).

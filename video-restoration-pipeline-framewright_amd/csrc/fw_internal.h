@@ -230,6 +230,10 @@ void launch_sca(const float* partial, int nblocks, long HW, int C, const float* 
                 hipStream_t st);
 void launch_f32_to_planar(DType dt, const float* x, long M, int C, void* out, hipStream_t st);
 
+// AESRGAN (aesrgan.hip): fp32 RGB [M][3] -> typed [M][32] (channels 3.. zero); fp32 [M][cstride] -> fp32 RGB [M][3]
+void launch_rgb_f32_to_nhwc(DType dt, const float* x, long M, void* out, hipStream_t st);
+void launch_take_rgb_f32(const float* src, int cstride, long M, float* out, hipStream_t st);
+
 // ---- TAP frame path + K8 blend kernels (frame_ops.hip) ---------------------------------------------------
 void launch_u8_to_nhwc_padded(DType dt, const uint8_t* in_bgr, int H, int W, int Hp, int Wp, void* out, hipStream_t st);
 void launch_tap_post(const uint8_t* in_bgr, const float* rgb, int H, int W, int Wp, int rgb_cstride, uint8_t* out_bgr,
