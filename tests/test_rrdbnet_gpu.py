@@ -375,8 +375,12 @@ def test_16bit_frames_follow_the_65535_branch(hip_lib, scale):
     rgba = np.concatenate([f16, f16[:, :, :1]], axis=2)
     oa, ma = up.enhance(rgba, outscale=scale)
     assert ma == "RGBA" and oa.shape[2] == 4 and oa.dtype == np.uint16 and np.array_equal(oa[:, :, :3], out)
-    with pytest.raises(NotImplementedError):
-        up.enhance(f16, outscale=scale / 2)
+    # outscale != netscale on the 16-bit frame: the uint16 result resized by OpenCV's float Lanczos path (round 1 raised here)
+    from oracle import lanczos_ref
+    half, mh = up.enhance(f16, outscale=scale / 2)
+    hw = (int(37 * scale / 2), int(50 * scale / 2))
+    assert mh == "RGB" and half.dtype == np.uint16 and half.shape == (hw[0], hw[1], 3)
+    assert np.array_equal(half, lanczos_ref.resize_lanczos4_u16(out, hw[1], hw[0]))
     eng.close()
 
 
