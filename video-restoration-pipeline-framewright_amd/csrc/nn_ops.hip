@@ -865,7 +865,126 @@ __global__ __launch_bounds__(256, 3) void dwconv3x3_gate_kernel(const T* __restr
     }
 }
 
+static bool dwconv_wide() {   // FW_NAF_DW_WIDE=0: the one-kernel-for-all-widths path (A/B)
+    static const bool on = [] {
+        const char* e = getenv("FW_NAF_DW_WIDE");
+        return !e || atoi(e) != 0;
+    }();
+    return on;
+}
+
+// The same kernel for C >= 256 (the low-resolution levels: 8 k ... 130 k pixels, 512 ... 2048 channels).  There every block of the
+// kernel above staged ALL 2C filters (72 KB at C = 1024, 768 blocks: 1.0 GB of the 5.6 GB the 28 launches of a forward moved, PMC)
+// because its 256 threads spanned every channel group.  Here a block owns 32 channel groups (256 gated channels: 18 KB of filters)
+// and walks columns; blocks b, b + 1, .. b + C/256 - 1 cover the channel ranges of one column set and write disjoint slices of one
+// `partial` row, so the SCA pooling stays a fixed-order sum over rows.
+template <typename T>
+__global__ __launch_bounds__(256, 3) void dwconv3x3_gate_wide_kernel(const T* __restrict__ x, int H, int W, int C, const float* wdw,
+                                                                     const float* bdw, T* out, float* partial) {
+    __shared__ __attribute__((aligned(16))) float wl[9 * 512];      // [tap][half][256 channels of this block's range]
+    __shared__ float red[256][8];
+    const int ngr = C / 256;                                        // channel ranges
+    const int gr = blockIdx.x % ngr, cb = blockIdx.x / ngr, ncb = gridDim.x / ngr;
+    for (int i = threadIdx.x; i < 9 * 512; i += 256) {
+        const int tap = i / 512, r = i - tap * 512, half = r >> 8;
+        wl[i] = wdw[(size_t)(half * C + gr * 256 + (r & 255)) * 9 + tap];
+    }
+    __syncthreads();
+    const int gl = threadIdx.x & 31, cl = threadIdx.x >> 5;         // channel group of the range, column of the block's eight
+    const int g = gr * 32 + gl;
+    const unsigned strips = (H + GATE_ROWS - 1) / GATE_ROWS;
+    const unsigned cols = strips * (unsigned)W;                     // (strip, x)
+    float cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    using V8 = typename Tr<T>::v8;
+    for (unsigned col = cb * 8 + cl; col < cols; col += ncb * 8) {
+        const int strip = (int)(col / (unsigned)W), xx = (int)(col - (unsigned)strip * W);
+        const int y0 = strip * GATE_ROWS;
+        float res[GATE_ROWS][8];
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            const int c0 = half * C + g * 8;
+            const float* wh = wl + half * 256 + gl * 8;
+            float acc[GATE_ROWS][8];
+#pragma unroll
+            for (int o = 0; o < GATE_ROWS; ++o)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[o][j] = bdw[c0 + j];
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int sx = xx + dx - 1;
+                const int cx = sx < 0 ? 0 : (sx >= W ? W - 1 : sx);
+                const bool cok = sx >= 0 && sx < W;
+                V8 f[GATE_ROWS + 2];
+#pragma unroll
+                for (int r = 0; r < GATE_ROWS + 2; ++r) {
+                    const int sy = y0 + r - 1;
+                    const int cy = sy < 0 ? 0 : (sy >= H ? H - 1 : sy);
+                    f[r] = __builtin_bit_cast(V8, *reinterpret_cast<const uint4*>(x + ((long)cy * W + cx) * (2 * C) + c0));
+                }
+                float wr[3][8];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wh + (dy * 3 + dx) * 512);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4*>(wh + (dy * 3 + dx) * 512 + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        wr[dy][j] = w0[j];
+                        wr[dy][4 + j] = w1[j];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < GATE_ROWS + 2; ++r) {
+                    const int sy = y0 + r - 1;
+                    const float m = (cok && sy >= 0 && sy < H) ? 1.f : 0.f;
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (float)f[r][j] * m;
+#pragma unroll
+                    for (int o = 0; o < GATE_ROWS; ++o) {
+                        const int dy = r - o;
+                        if (dy >= 0 && dy < 3) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[o][j] += v[j] * wr[dy][j];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < GATE_ROWS; ++o)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) res[o][j] = half ? res[o][j] * acc[o][j] : acc[o][j];
+        }
+#pragma unroll
+        for (int o = 0; o < GATE_ROWS; ++o) {
+            if (y0 + o >= H) continue;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cs[j] += res[o][j];
+            *reinterpret_cast<uint4*>(out + ((long)(y0 + o) * W + xx) * C + g * 8) = pack8f<T>(res[o]);
+        }
+    }
+    if (partial) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = cs[j];
+        __syncthreads();
+        // channel c of the range = group c / 8, element c % 8: the eight threads gl, gl + 32, ... hold its column sums
+        const int gg = threadIdx.x >> 3, j = threadIdx.x & 7;
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) sum += red[gg + 32 * t][j];
+        partial[(long)cb * C + gr * 256 + threadIdx.x] = sum;
+    }
+}
+
+// rows of `partial` the depthwise kernel writes (= the workgroups that cover one channel range)
+static int dwconv_wide_rows(int H, int W, int C) {
+    const long cols = (long)((H + GATE_ROWS - 1) / GATE_ROWS) * W;
+    const long want = (cols + 7) / 8;
+    const long cap = DW_MAX_BLOCKS / (C / 256);
+    return (int)(want < cap ? want : cap);
+}
+
 int dwconv_blocks(int H, int W, int C) {
+    if (C >= 256 && dwconv_wide()) return dwconv_wide_rows(H, W, C);
     const long total = (long)((H + GATE_ROWS - 1) / GATE_ROWS) * W * (C / 8);
     const long b = (total + 255) / 256;
     return (int)(b < DW_MAX_BLOCKS ? b : DW_MAX_BLOCKS);
@@ -874,6 +993,17 @@ int dwconv_blocks(int H, int W, int C) {
 void launch_dwconv3x3_gate(DType dt, const void* x, int H, int W, int C, const float* wdw, const float* bdw, void* out,
                            float* partial, hipStream_t st) {
     if (C < 32 || (C & (C - 1)) || C > 1024) throw Error(1, "dwconv3x3_gate: C must be a power of two in [32, 1024]");
+    if (C >= 256 && dwconv_wide()) {
+        const int grid = dwconv_wide_rows(H, W, C) * (C / 256);
+        if (dt == DT_BF16)
+            hipLaunchKernelGGL((dwconv3x3_gate_wide_kernel<__bf16>), dim3((unsigned)grid), dim3(256), 0, st, (const __bf16*)x, H, W, C, wdw, bdw,
+                               (__bf16*)out, partial);
+        else
+            hipLaunchKernelGGL((dwconv3x3_gate_wide_kernel<_Float16>), dim3((unsigned)grid), dim3(256), 0, st, (const _Float16*)x, H, W, C, wdw, bdw,
+                               (_Float16*)out, partial);
+        FW_HIP_CHECK(hipGetLastError());
+        return;
+    }
     const int blocks = dwconv_blocks(H, W, C);
     const size_t smem = ((size_t)18 * C + 256 * 8) * sizeof(float);  // filters [9][2C] + pooling scratch (<= 80 KiB)
     static const bool attr_set = [] {
