@@ -1,0 +1,123 @@
+// Diagnostic only (tools/winograd_kloop.py): the inner loop of the Winograd F(2x2, 3x3) trunk kernel DESIGN.md section 8 sketches,
+// on static random f16 data in LDS - no DMA, no epilogue - to MEASURE what the paper design's K loop sustains before anything is
+// built on it.  One "chunk" = 32 input channels of an 8 x 32-pixel output tile (64 Winograd tiles = 4 pixel tiles of 16) into 64
+// output channels; wave i owns the four frequencies (i, l) of transform row i:
+//   per pixel tile: 8 ds_read_b128 of the two raw halo rows the row transform needs (columns de-interleaved by parity so that 16
+//   lanes on 16 consecutive tiles read 16 consecutive pieces), two v_pk_add_f16 stages -> 4 B fragments, 16 v_mfma_f32_16x16x32_f16
+//   against the wave's 16 weight fragments (held in registers for the chunk).
+// NW = 4: one wave per SIMD, 4 pixel tiles per wave, 256 accumulator registers; NW = 8: two waves per SIMD, 2 pixel tiles each.
+// The direct kernel spends ~3500 cycles on the same 256 pixels x 32 channels x 64 outputs.
+#include "fw_internal.h"
+#include "../../include/framewright_hip.h"
+
+namespace {
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+constexpr int RAW_PIECES = 10 * 4 * 2 * 17;   // [row 10][slot 4][parity 2][17] 16-byte pieces
+constexpr int W_PIECES = 4 * 16 * 64;         // [frequency row 4][l 4][cout tile 4][lane 64]
+
+template <int NW, bool SYNC>
+__global__ __launch_bounds__(64 * NW, NW / 4) void winograd_kloop_kernel(const uint4* __restrict__ seed, int iters, float* sink,
+                                                                         unsigned long long* clocks) {
+    __shared__ __attribute__((aligned(16))) uint4 raw[RAW_PIECES];
+    __shared__ __attribute__((aligned(16))) uint4 wl[W_PIECES];
+    for (int i = threadIdx.x; i < RAW_PIECES; i += 64 * NW) raw[i] = seed[i & 1023];
+    for (int i = threadIdx.x; i < W_PIECES; i += 64 * NW) wl[i] = seed[(i * 7 + 3) & 1023];
+    __syncthreads();
+    constexpr int PT = 16 / NW;               // pixel tiles per wave
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, q = lane & 15, sl = lane >> 4;
+    const int fi = wave & 3, p0 = (wave >> 2) * PT;
+    // rows of the 4x4 patch the row transform of frequency row fi combines: (0,2) (1,2) (2,1) (1,3); signs + - ... see below
+    const int j1 = fi == 0 ? 0 : (fi == 2 ? 2 : 1), j2 = fi == 0 ? 2 : (fi == 1 ? 2 : (fi == 2 ? 1 : 3));
+    const bool add = fi == 1;                 // r = d[j1] + d[j2] for row 1, d[j1] - d[j2] otherwise
+    f4 acc[4][PT][4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[l][p][ct] = f4{0, 0, 0, 0};
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+        uint4 U[4][4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) U[l][ct] = wl[((fi * 4 + l) * 4 + ct) * 64 + lane];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const int rbase = 2 * (p0 + p);
+            h8 r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {     // column 2 q + k of rows rbase + j1 / j2: parity k & 1, index q + (k >> 1)
+                const uint4 a = raw[(((rbase + j1) * 4 + sl) * 2 + (k & 1)) * 17 + q + (k >> 1)];
+                const uint4 b = raw[(((rbase + j2) * 4 + sl) * 2 + (k & 1)) * 17 + q + (k >> 1)];
+                const h8 ha = __builtin_bit_cast(h8, a), hb = __builtin_bit_cast(h8, b);
+                r[k] = add ? ha + hb : ha - hb;
+            }
+            const h8 V[4] = {r[0] - r[2], r[1] + r[2], r[2] - r[1], r[1] - r[3]};
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    acc[l][p][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, U[l][ct]), V[l], acc[l][p][ct], 0, 0, 0);
+        }
+        if (SYNC) __syncthreads();            // the raw tile of the next chunk would be published here
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float out = 0.f;
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) out += acc[l][p][ct][0];
+    if (out == 123.456f) sink[0] = out;
+    if (threadIdx.x == 0) {
+        atomicAdd(clocks, c1 - c0);
+        atomicAdd(clocks + 1, r1 - r0);
+    }
+}
+}  // namespace
+
+// `iters` chunks on `blocks` workgroups of `waves` (4 or 8) waves; ms of the launch and the summed s_memtime / s_memrealtime deltas
+// of thread 0 of every workgroup
+extern "C" int fw_debug_winograd_kloop(int waves, int sync, int blocks, int iters, float* ms_out, unsigned long long* clocks_out) {
+    if ((waves != 4 && waves != 8) || blocks < 1 || iters < 1 || !ms_out || !clocks_out) return FW_ERR_INVALID;
+    uint4* seed = nullptr;
+    float* sink = nullptr;
+    unsigned long long* clk = nullptr;
+    if (hipMalloc((void**)&seed, 1024 * 16) != hipSuccess || hipMalloc((void**)&sink, 4) != hipSuccess || hipMalloc((void**)&clk, 16) != hipSuccess)
+        return FW_ERR_OOM;
+    uint16_t h[8192];
+    unsigned s = 12345u;
+    for (int i = 0; i < 8192; ++i) {          // random f16 in roughly [-2, 2)
+        s = s * 1664525u + 1013904223u;
+        h[i] = (uint16_t)(((s >> 16) & 0x8000u) | ((13u + ((s >> 8) & 3u)) << 10) | ((s >> 20) & 0x3ffu));
+    }
+    (void)hipMemcpy(seed, h, sizeof(h), hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    for (int rep = 0; rep < 2; ++rep) {
+        if (rep == 1) {
+            (void)hipMemset(clk, 0, 16);
+            (void)hipEventRecord(e0, nullptr);
+        }
+        if (waves == 4 && sync) hipLaunchKernelGGL((winograd_kloop_kernel<4, true>), dim3(blocks), dim3(256), 0, nullptr, seed, iters, sink, clk);
+        else if (waves == 4) hipLaunchKernelGGL((winograd_kloop_kernel<4, false>), dim3(blocks), dim3(256), 0, nullptr, seed, iters, sink, clk);
+        else if (sync) hipLaunchKernelGGL((winograd_kloop_kernel<8, true>), dim3(blocks), dim3(512), 0, nullptr, seed, iters, sink, clk);
+        else hipLaunchKernelGGL((winograd_kloop_kernel<8, false>), dim3(blocks), dim3(512), 0, nullptr, seed, iters, sink, clk);
+    }
+    (void)hipEventRecord(e1, nullptr);
+    const int rc = hipEventSynchronize(e1) == hipSuccess ? FW_OK : FW_ERR_HIP;
+    (void)hipEventElapsedTime(ms_out, e0, e1);
+    (void)hipMemcpy(clocks_out, clk, 16, hipMemcpyDeviceToHost);
+    (void)hipFree(seed);
+    (void)hipFree(sink);
+    (void)hipFree(clk);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
