@@ -9,6 +9,8 @@ bar?  The 23-block x4 generator on a crop, three ways against the fp32 oracle:
             rounded to f16 (U = G g G^T), elementwise products summed over channels in fp32, output transform in fp32;
   winograd_v32  the same with V kept in fp32 (only U rounded): what a tf32-like / split operand would give.
 
+  winograd_f4x4 / _v32  F(4x4, 3x3) the same two ways (4x fewer MACs, far larger transform constants).
+
 Prints max-abs and PSNR of each against fp32.  Uses seeded synthetic weights (the tests' generator)."""
 import sys, math
 from pathlib import Path
@@ -22,25 +24,32 @@ h16 = lambda t: t.to(torch.float16).to(torch.float32)
 BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float32)
 G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float32)
 AT = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float32)
+# F(4x4, 3x3), Lavin & Gray's matrices: 36 products per 16 outputs (4x fewer MACs than direct), constants up to 8 and 1/24
+BT6 = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]],
+                   dtype=torch.float32)
+G6 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]],
+                  dtype=torch.float32)
+AT6 = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=torch.float32)
 
 
 def conv_direct(x, w, b):
     return F.conv2d(h16(x), h16(w), b, padding=1)
 
 
-def conv_winograd(x, w, b, round_v=True):
+def conv_winograd(x, w, b, round_v=True, m=2):
     n, c, H, W = x.shape
-    assert H % 2 == 0 and W % 2 == 0
+    assert H % m == 0 and W % m == 0
+    bt, g, at = (BT, G, AT) if m == 2 else (BT6, G6, AT6)
     xp = F.pad(h16(x), (1, 1, 1, 1))
-    tiles = xp.unfold(2, 4, 2).unfold(3, 4, 2)                     # n c th tw 4 4
-    V = torch.einsum("ij,nctujk,lk->nctuil", BT, tiles, BT)        # B^T d B
+    tiles = xp.unfold(2, m + 2, m).unfold(3, m + 2, m)             # n c th tw (m+2) (m+2)
+    V = torch.einsum("ij,nctujk,lk->nctuil", bt, tiles, bt)        # B^T d B
     if round_v:
         V = h16(V)
-    U = h16(torch.einsum("ij,ocjk,lk->ocil", G, w, G))             # G g G^T, rounded
+    U = h16(torch.einsum("ij,ocjk,lk->ocil", g, w, g))             # G g G^T, rounded
     Mm = torch.einsum("ocil,nctuil->notuil", U, V)                 # sum over channels, fp32
-    Y = torch.einsum("ij,notujk,lk->notuil", AT, Mm, AT)           # n o th tw 2 2
+    Y = torch.einsum("ij,notujk,lk->notuil", at, Mm, at)           # n o th tw m m
     th, tw = Y.shape[2], Y.shape[3]
-    y = Y.permute(0, 1, 2, 4, 3, 5).reshape(n, w.shape[0], th * 2, tw * 2)
+    y = Y.permute(0, 1, 2, 4, 3, 5).reshape(n, w.shape[0], th * m, tw * m)
     return y + b.view(1, -1, 1, 1)
 
 
@@ -75,7 +84,8 @@ def main():
     x = torch.from_numpy(frame[:, :, ::-1].astype(np.float32) / 255.0).permute(2, 0, 1).unsqueeze(0)
     with torch.no_grad():
         want = ref.rrdbnet_forward(sd, x, nb, 4)
-        for name, fn in (("direct", conv_direct), ("winograd", conv_winograd), ("winograd_v32", lambda a, w, b: conv_winograd(a, w, b, False))):
+        for name, fn in (("direct", conv_direct), ("winograd", conv_winograd), ("winograd_v32", lambda a, w, b: conv_winograd(a, w, b, False)),
+                         ("winograd_f4x4", lambda a, w, b: conv_winograd(a, w, b, True, 4)), ("winograd_f4x4_v32", lambda a, w, b: conv_winograd(a, w, b, False, 4))):
             got = forward(sd, x, nb, fn)
             d = (got - want).abs()
             mse = float(((got.clamp(0, 1) - want.clamp(0, 1)) ** 2).mean())
