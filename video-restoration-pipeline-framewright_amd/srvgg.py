@@ -12,7 +12,7 @@ into the epilogue); the last conv leaves fp32, and one small kernel does PixelSh
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Mapping, Optional, Tuple
+from typing import List, Mapping, Tuple
 
 import numpy as np
 
