@@ -42,7 +42,7 @@ def test_layernorm(hip_lib, dtype, C_, ld):
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
-@pytest.mark.parametrize("mode,Cc", [(0, 192), (1, 256)])
+@pytest.mark.parametrize("mode,Cc", [(0, 192), (1, 256), (0, 576), (0, 1152), (1, 1024), (1, 2048)])   # from 512 output channels: the channel-range kernel
 def test_dwconv3x3(hip_lib, dtype, mode, Cc):
     g = torch.Generator().manual_seed(mode + Cc)
     H, W = 13, 21

@@ -231,6 +231,100 @@ __global__ __launch_bounds__(256, 2) void dwconv3x3_nhwc_kernel(const T* __restr
         }
 }
 
+// The same kernel for the many-channel levels (192 / 384 channels on 128^2 / 64^2 pixels: 576 ... 2048 depthwise channels).  There
+// every one of the up to 512 blocks of the kernel above staged ALL filters (72 KB at 2048 channels) because its 256 threads spanned
+// every channel group.  Here a block owns 32 channel groups (256 output channels: 9 or 18 KB of filters) and walks columns.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256, 2) void dwconv3x3_nhwc_wide_kernel(const T* __restrict__ x, long ldx, int H, int W, int C,
+                                                                  const float* __restrict__ wdw, T* out, long ldo) {
+    constexpr int HALVES = MODE == 1 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) float dw_w[9 * HALVES * 256];   // [tap][half][256 channels of this block's range]
+    const int Co = MODE == 1 ? C / 2 : C;
+    const int groups = Co / 8, ngr = (groups + 31) / 32;
+    const int gr = blockIdx.x % ngr, cb = blockIdx.x / ngr, ncb = gridDim.x / ngr;
+    for (int i = threadIdx.x; i < 9 * HALVES * 256; i += 256) {
+        const int tap = i / (HALVES * 256), r = i - tap * (HALVES * 256), half = r >> 8, ch = gr * 256 + (r & 255);
+        dw_w[i] = ch < Co ? wdw[(size_t)(half * Co + ch) * 9 + tap] : 0.f;
+    }
+    __syncthreads();
+    const int gl = threadIdx.x & 31, cl = threadIdx.x >> 5;
+    const int g = gr * 32 + gl;
+    if (g >= groups) return;
+    using V = typename V8<T>::t;
+    const int strips = (H + DW_ROWS - 1) / DW_ROWS;
+    for (int strip = blockIdx.y; strip < strips; strip += gridDim.y)
+        for (int xx = cb * 8 + cl; xx < W; xx += ncb * 8) {
+            const int y0 = strip * DW_ROWS;
+            float res[DW_ROWS][8];
+#pragma unroll 1
+            for (int half = 0; half < HALVES; ++half) {
+                const int c0 = half * Co + g * 8;
+                const float* wh = dw_w + half * 256 + gl * 8;
+                float wr[9][8];  // [tap][channel]
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float4 w0 = *reinterpret_cast<const float4*>(wh + t * HALVES * 256);
+                    const float4 w1 = *reinterpret_cast<const float4*>(wh + t * HALVES * 256 + 4);
+                    wr[t][0] = w0.x, wr[t][1] = w0.y, wr[t][2] = w0.z, wr[t][3] = w0.w;
+                    wr[t][4] = w1.x, wr[t][5] = w1.y, wr[t][6] = w1.z, wr[t][7] = w1.w;
+                }
+                float acc[DW_ROWS][8];
+#pragma unroll
+                for (int o = 0; o < DW_ROWS; ++o)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[o][j] = 0.f;
+#pragma unroll
+                for (int r = 0; r < DW_ROWS + 2; ++r) {
+                    const int sy = y0 + r - 1;
+                    const bool rok = sy >= 0 && sy < H;
+                    const int cy = sy < 0 ? 0 : (sy >= H ? H - 1 : sy);
+                    V f[3];
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int sx = xx + dx - 1;
+                        const int cx = sx < 0 ? 0 : (sx >= W ? W - 1 : sx);
+                        f[dx] = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(x + ((long)cy * W + cx) * ldx + c0));
+                    }
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int sx = xx + dx - 1;
+                        const float m = (rok && sx >= 0 && sx < W) ? 1.f : 0.f;
+                        float v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = (float)f[dx][j] * m;
+#pragma unroll
+                        for (int o = 0; o < DW_ROWS; ++o) {
+                            const int dy = r - o;
+                            if (dy >= 0 && dy < 3) {
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) acc[o][j] += v[j] * wr[dy * 3 + dx][j];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = 0; o < DW_ROWS; ++o)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (MODE == 1 && half == 0)
+                            res[o][j] = 0.5f * acc[o][j] * (1.0f + erff(acc[o][j] * 0.70710678118654752f));
+                        else if (MODE == 1)
+                            res[o][j] *= acc[o][j];
+                        else
+                            res[o][j] = acc[o][j];
+                    }
+            }
+#pragma unroll
+            for (int o = 0; o < DW_ROWS; ++o) {
+                if (y0 + o >= H) continue;
+                V ov;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ov[j] = (T)res[o][j];
+                *reinterpret_cast<uint4*>(out + ((long)(y0 + o) * W + xx) * ldo + g * 8) = __builtin_bit_cast(uint4, ov);
+            }
+        }
+}
+
 // ---- MDTA Gram matrices ---------------------------------------------------------------------------------------------------
 // qkv typed [M][ld]: q at channel 0, k at k_off; `dim` = heads * ch channels each.  partial[block][dim*ch + 2*dim]:
 //   [h][c1][c2] = sum_p q[p][h*ch+c1] * k[p][h*ch+c2] over the block's pixels, then sum q^2 and sum k^2 per channel.
@@ -796,6 +890,28 @@ int fw_dwconv3x3_nhwc(int dtype, const void* x, long ldx, int H, int W, int chan
     return rguard([&] {
         const int co = mode == 1 ? channels / 2 : channels;
         const int strips = (H + fw::DW_ROWS - 1) / fw::DW_ROWS;
+        static const bool wide_on = [] {   // FW_REST_DW_WIDE=0: one kernel for all widths (A/B)
+            const char* e = getenv("FW_REST_DW_WIDE");
+            return !e || atoi(e) != 0;
+        }();
+        if (wide_on && co >= 512) {
+            const int ngr = (co / 8 + 31) / 32;
+            int ncb = (W + 7) / 8;
+            const int cap = 512 / ngr > 0 ? 512 / ngr : 1;               // about one round of resident blocks over (columns x strips)
+            int by = strips;
+            if (ncb * by > cap) {
+                by = cap / ncb > 0 ? cap / ncb : 1;
+                if (ncb * by > cap) ncb = cap;
+            }
+            const dim3 grid((unsigned)(ncb * ngr), (unsigned)by);
+            hipStream_t st = (hipStream_t)stream;
+#define FW_DWW(T, MO) hipLaunchKernelGGL((dwconv3x3_nhwc_wide_kernel<T, MO>), grid, dim3(256), 0, st, (const T*)x, ldx, H, W, channels, weight, (T*)out, ldo)
+            if (dtype == FW_DTYPE_BF16) { if (mode) FW_DWW(__bf16, 1); else FW_DWW(__bf16, 0); }
+            else { if (mode) FW_DWW(_Float16, 1); else FW_DWW(_Float16, 0); }
+#undef FW_DWW
+            FW_HIP_CHECK(hipGetLastError());
+            return;
+        }
         const int bx = blocks_for((long)W * (co / 8), 1024);
         const int by_cap = 512 / bx > 0 ? 512 / bx : 1;   // one round of the 512 resident blocks: every block stages the filters in LDS first, so few fat blocks
         const dim3 blocks(bx, strips < by_cap ? strips : by_cap);
