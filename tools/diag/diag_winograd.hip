@@ -88,7 +88,8 @@ constexpr int RAW_KIB = 22;                      // raw tile padded to 22 KiB in
 // WREG: the weight slices go straight from L2 into registers with plain 16-byte loads (one chunk ahead) instead of through LDS-DMA.
 template <bool WREG>
 __global__ __launch_bounds__(256, 1) void winograd_stream_kernel(const char* __restrict__ wsrc, const char* __restrict__ rsrc, long rtiles, int iters,
-                                                                 float* sink, unsigned long long* clocks) {
+                                                                 int stagger /* workgroup b starts at weight chunk b % 6 */, float* sink,
+                                                                 unsigned long long* clocks) {
     __shared__ __attribute__((aligned(16))) uint4 raw[2][RAW_KIB * 64];
     __shared__ __attribute__((aligned(16))) uint4 wl[W_PIECES];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, q = lane & 15, sl = lane >> 4;
@@ -96,8 +97,9 @@ __global__ __launch_bounds__(256, 1) void winograd_stream_kernel(const char* __r
     const int fi = wave;
     const int j1 = fi == 0 ? 0 : (fi == 2 ? 2 : 1), j2 = fi == 0 ? 2 : (fi == 1 ? 2 : (fi == 2 ? 1 : 3));
     const bool add = fi == 1;
+    const int cph = stagger ? (int)(blockIdx.x % 6) : 0;
     auto fetch_w = [&](int chunk) {            // this wave's slice of chunk `chunk % 6`: 16 KiB in four batches of four pieces
-        const char* src = wsrc + ((size_t)(chunk % 6) * 4 + fi) * 16384;
+        const char* src = wsrc + ((size_t)((chunk + cph) % 6) * 4 + fi) * 16384;
 #pragma unroll
         for (int k = 0; k < 4; ++k) fw::glds16_batch_w<4>(src + 4096 * (k + 1), lane * 16, w_lds + fi * 16384 + 4096 * (k + 1));
     };
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(256, 1) void winograd_stream_kernel(const char* __r
     const long t0 = (long)blockIdx.x * iters;
     uint4 Un[4][4];
     auto load_w = [&](int chunk) {
-        const uint4* src = reinterpret_cast<const uint4*>(wsrc + ((size_t)(chunk % 6) * 4 + fi) * 16384) + lane;
+        const uint4* src = reinterpret_cast<const uint4*>(wsrc + ((size_t)((chunk + cph) % 6) * 4 + fi) * 16384) + lane;
 #pragma unroll
         for (int l = 0; l < 4; ++l)
 #pragma unroll
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256, 1) void winograd_stream_kernel(const char* __r
 }  // namespace
 
 // the streaming variant: `iters` chunks per workgroup, raw tiles from a buffer of `raw_mib` MiB (0: one tile re-read: L2), ms + clocks
-extern "C" int fw_debug_winograd_stream(int wreg, int blocks, int iters, int raw_mib, float* ms_out, unsigned long long* clocks_out) {
+extern "C" int fw_debug_winograd_stream(int wreg, int stagger, int blocks, int iters, int raw_mib, float* ms_out, unsigned long long* clocks_out) {
     if (blocks < 1 || iters < 1 || raw_mib < 0 || !ms_out || !clocks_out) return FW_ERR_INVALID;
     const size_t wbytes = 6 * 65536, rbytes = raw_mib > 0 ? (size_t)raw_mib << 20 : (size_t)RAW_KIB * 1024;
     const long rtiles = (long)(rbytes / (RAW_KIB * 1024));
@@ -205,8 +207,8 @@ extern "C" int fw_debug_winograd_stream(int wreg, int blocks, int iters, int raw
             (void)hipMemset(clk, 0, 16);
             (void)hipEventRecord(e0, nullptr);
         }
-        if (wreg) hipLaunchKernelGGL(winograd_stream_kernel<true>, dim3(blocks), dim3(256), 0, nullptr, (const char*)w, (const char*)r, rtiles, iters, sink, clk);
-        else hipLaunchKernelGGL(winograd_stream_kernel<false>, dim3(blocks), dim3(256), 0, nullptr, (const char*)w, (const char*)r, rtiles, iters, sink, clk);
+        if (wreg) hipLaunchKernelGGL(winograd_stream_kernel<true>, dim3(blocks), dim3(256), 0, nullptr, (const char*)w, (const char*)r, rtiles, iters, stagger, sink, clk);
+        else hipLaunchKernelGGL(winograd_stream_kernel<false>, dim3(blocks), dim3(256), 0, nullptr, (const char*)w, (const char*)r, rtiles, iters, stagger, sink, clk);
     }
     (void)hipEventRecord(e1, nullptr);
     const int rc = hipEventSynchronize(e1) == hipSuccess ? FW_OK : FW_ERR_HIP;

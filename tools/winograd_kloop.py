@@ -23,15 +23,25 @@ for waves in (4, 8):
         res[f"waves{waves}_sync{sync}"] = {"ms": ms.value, "cycles_per_chunk": clk[0] / blocks / iters, "clock_ghz": clk[0] / max(clk[1], 1) * 0.1,
                                           "direct_equivalent_tflops": blocks * iters * direct_flop / (ms.value * 1e-3) / 1e12}
 lib.fw_debug_winograd_stream.restype = C.c_int
-lib.fw_debug_winograd_stream.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_ulonglong)]
+lib.fw_debug_winograd_stream.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_ulonglong)]
 # with the data movement: weight slices re-fetched from an L2-resident buffer every chunk, raw tiles from one tile (L2) or a 2-GiB buffer (HBM)
 # ("wreg": the weight slices by plain 16-byte loads straight into registers, one chunk ahead, instead of LDS-DMA)
-for name, wreg, mib in (("stream_wdma_raw_l2", 0, 0), ("stream_wdma_raw_hbm", 0, 2048), ("stream_wreg_raw_l2", 1, 0), ("stream_wreg_raw_hbm", 1, 2048)):
+# ("stag": workgroup b starts at weight chunk b % 6, so that the CUs of an XCD do not all ask for the same lines at the same time)
+for name, wreg, stag, mib in (("stream_wdma_raw_l2", 0, 0, 0), ("stream_wdma_raw_hbm", 0, 0, 2048), ("stream_wreg_raw_l2", 1, 0, 0), ("stream_wreg_raw_hbm", 1, 0, 2048),
+                              ("stream_wdma_stag_raw_hbm", 0, 1, 2048), ("stream_wreg_stag_raw_hbm", 1, 1, 2048)):
     ms, clk = C.c_float(), (C.c_ulonglong * 2)()
     it = 4000
-    assert lib.fw_debug_winograd_stream(wreg, blocks, it, mib, C.byref(ms), clk) == 0
+    assert lib.fw_debug_winograd_stream(wreg, stag, blocks, it, mib, C.byref(ms), clk) == 0
     ghz = clk[0] / max(clk[1], 1) * 0.1
     res[name] = {"ms": ms.value, "cycles_per_chunk": ms.value * 1e-3 / it * ghz * 1e9, "clock_ghz": ghz,
                  "direct_equivalent_tflops": blocks * it * direct_flop / (ms.value * 1e-3) / 1e12,
                  "l2_to_lds_tb_per_s": blocks * it * (65536 + 22 * 1024) / (ms.value * 1e-3) / 1e12}
+# is that rate a limit of the chip or of one CU?  The same kernel on 32 .. 256 workgroups (round-robin over the XCDs: 4 .. 32 CUs each)
+for nb in (32, 64, 128, 256):
+    ms, clk = C.c_float(), (C.c_ulonglong * 2)()
+    it = 4000
+    assert lib.fw_debug_winograd_stream(0, 0, nb, it, 2048, C.byref(ms), clk) == 0
+    ghz = clk[0] / max(clk[1], 1) * 0.1
+    res[f"stream_wdma_raw_hbm_blocks{nb}"] = {"ms": ms.value, "cycles_per_chunk": ms.value * 1e-3 / it * ghz * 1e9, "clock_ghz": ghz,
+                                               "gb_per_s_per_cu": it * (65536 + 22 * 1024) / (ms.value * 1e-3) / 1e9}
 print(json.dumps(res, indent=1))

@@ -582,12 +582,27 @@ __global__ __launch_bounds__(128) void attn_finish_kernel(const float* __restric
     const int c2 = threadIdx.x;
     if (c2 < ch) {
         // the last level of the reduction happens here: rows 0 .. rows-1 of the workspace, in order (deterministic)
+        // (loads of eight rows in flight at a time; the adds stay in row order.  Before: one row per L2 round trip, 10.6 us per launch)
         float g = 0.f, kn = 0.f, qn = 0.f;
-        for (int b = 0; b < rows; ++b) {
-            const float* sb = sums + (size_t)b * stride;
-            g += sb[(h * ch + c1) * ch + c2];
-            kn += sb[dim * ch + dim + h * ch + c2];
-            qn += sb[dim * ch + h * ch + c1];
+        const float* s0 = sums + (h * ch + c1) * ch + c2;
+        const float* s1 = sums + dim * ch + dim + h * ch + c2;
+        const float* s2 = sums + dim * ch + h * ch + c1;
+        int b = 0;
+        for (; b + 8 <= rows; b += 8) {
+            float gv[8], kv[8], qv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                gv[u] = s0[(size_t)(b + u) * stride];
+                kv[u] = s1[(size_t)(b + u) * stride];
+                qv[u] = s2[(size_t)(b + u) * stride];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g += gv[u], kn += kv[u], qn += qv[u];
+        }
+        for (; b < rows; ++b) {
+            g += s0[(size_t)b * stride];
+            kn += s1[(size_t)b * stride];
+            qn += s2[(size_t)b * stride];
         }
         const float dq = fmaxf(sqrtf(qn), 1e-12f), dk = fmaxf(sqrtf(kn), 1e-12f);
         row[c2] = g / (dq * dk) * temperature[h];
@@ -652,7 +667,16 @@ __global__ __launch_bounds__(256) void attn_proj_pack_kernel(const float* __rest
             const int h = k / ch, c2 = k - h * ch;
             const float* w = wp + (size_t)co * dim + h * ch;
             const float* a = attn + (size_t)h * ch * ch + c2;
-            for (int c1 = 0; c1 < ch; ++c1) v += w[c1] * a[(size_t)c1 * ch];
+            // 16 products' loads in flight at a time, summed in c1 order (before: one c1 per L2 round trip, 14.9 us per launch)
+            int c1 = 0;
+            for (; c1 + 16 <= ch; c1 += 16) {
+                float wv[16], av[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) wv[u] = w[c1 + u], av[u] = a[(size_t)(c1 + u) * ch];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v += wv[u] * av[u];
+            }
+            for (; c1 < ch; ++c1) v += w[c1] * a[(size_t)c1 * ch];
         }
         dst[i] = (T)v;
     }
