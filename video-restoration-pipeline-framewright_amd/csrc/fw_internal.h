@@ -205,15 +205,15 @@ struct PwDwParams {
     void* out;             // typed NHWC, ldo elements per pixel: N channels (PWDW_NONE) or N / 2 (gate modes)
     long ldo;
     float* partial;        // PWDW_GATE_MUL: [pw_dw_blocks][N / 2] sums of the gated output (SCA pooling), or null
-    // PWDW_NONE, Restormer's qkv: chunks [0, t_chunks) are q and [t_chunks, 2 t_chunks) are k; with qT / kT set they are written ONLY
+    // PWDW_NONE, Restormer's qkv: with qT set, chunks [0, t_chunks) (q, then k: channel rows 64 j of chunk j) are written ONLY
     // there, as [pixel group of 8][t_ld channels][8 pixels] - the operand layout of the Gram kernel (attn_gram_mfma_kernel) - with
-    // the pixels in tile order: tile t owns groups [56 t, 56 t + 56) (14 x 30 pixels row-major, zero padded to 448)
+    // the pixels in tile order: tile t owns groups [56 t, 56 t + 56) (14 x 30 pixels row-major, zero padded to 448); the chunks
+    // behind them (v) go to `out` from its channel 0 on.  q and k need not be whole chunks each (96 + 96 channels = 3 chunks).
     void* qT;
-    void* kT;
     int t_chunks;
     long t_ld;
 };
-long pw_dw_transposed_pixels(int H, int W);   // pixels of qT / kT including the padding (a multiple of 32)
+long pw_dw_transposed_pixels(int H, int W);   // pixels of qT including the padding (a multiple of 32)
 void launch_attn_matrix_from_transposed(DType dt, const void* qT, const void* kT, long Mp, int ldc, int heads, int ch, const float* temperature,
                                         float* workspace, float* attn, hipStream_t st);
 bool pw_dw_eligible(int cin, int mode);

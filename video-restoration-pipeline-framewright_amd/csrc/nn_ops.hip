@@ -349,11 +349,12 @@ static void launch_pw_typed(const PointwiseParams& p, hipStream_t st) {
     hipLaunchKernelGGL((pointwise_mfma_kernel<T, CT, MODE>), dim3((unsigned)(mb * ((p.N_tiles + CT - 1) / CT))), \
                        block, 0, st, p)
     switch (p.mode) {
+        // (3 tiles = 96 output channels, Restormer's second level: one workgroup per pixel tile instead of two that both read it)
         case PW_STORE:
-            if (p.N_tiles >= 4) FW_PW(4, PW_STORE); else FW_PW(2, PW_STORE);
+            if (p.N_tiles >= 4) FW_PW(4, PW_STORE); else if (p.N_tiles == 3) FW_PW(3, PW_STORE); else FW_PW(2, PW_STORE);
             break;
         case PW_RESIDUAL:
-            if (p.N_tiles >= 4) FW_PW(4, PW_RESIDUAL); else FW_PW(2, PW_RESIDUAL);
+            if (p.N_tiles >= 4) FW_PW(4, PW_RESIDUAL); else if (p.N_tiles == 3) FW_PW(3, PW_RESIDUAL); else FW_PW(2, PW_RESIDUAL);
             break;
         case PW_SHUFFLE_UP:
             if (p.N_tiles >= 4) FW_PW(4, PW_SHUFFLE_UP); else FW_PW(2, PW_SHUFFLE_UP);

@@ -303,11 +303,10 @@ __global__ __launch_bounds__(512, 2) void pw_dw_kernel(const PwDwParams p) {
             FW_PH(6);
 #ifndef FW_FRONT_ABL_STORE   // timing only: no stores (the sums keep the arithmetic alive)
             bool transposed = false;
-            if constexpr (MODE == PWDW_NONE) transposed = p.qT && j < 2 * p.t_chunks;
+            if constexpr (MODE == PWDW_NONE) transposed = p.qT && j < p.t_chunks;
             if (transposed) {
                 // q / k for the Gram kernel: 16 bytes = 8 pixels of one channel, pixels in tile order, zeros where the tile has none
-                const bool is_k = j >= p.t_chunks;
-                T* dst = reinterpret_cast<T*>(is_k ? p.kT : p.qT) + 64 * 8 * (is_k ? j - p.t_chunks : j);
+                T* dst = reinterpret_cast<T*>(p.qT) + 64 * 8 * j;
                 constexpr int GROUPS = (FR_OR * FR_OC + 7) / 8 + 3;   // 56: 448 pixels, a multiple of 32
                 // a wave handles one pixel group per round (lane = channel): which pixels, and whether they exist, is scalar work
                 const char* ych = ybuf + FR_PXB * (FR_HC + 1) + 2 * lane;
@@ -330,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void pw_dw_kernel(const PwDwParams p) {
                 }
             } else {
                 constexpr int PPX = OUT_B / 16;               // 16-byte pieces per pixel
-                T* obase = reinterpret_cast<T*>(p.out) + (OUT_B / 2) * j;
+                T* obase = reinterpret_cast<T*>(p.out) + (OUT_B / 2) * (j - (MODE == PWDW_NONE && p.qT ? p.t_chunks : 0));
 #pragma unroll
                 for (int k = 0; k < (FR_OR * FR_OC * PPX + 511) / 512; ++k) {
                     const int i = tid + 512 * k;              // (output pixel, piece)
@@ -403,8 +402,7 @@ bool pw_dw_eligible(int cin, int mode) {
 
 void launch_pw_dw(DType dt, const PwDwParams& p, hipStream_t st) {
     if (!pw_dw_eligible(p.cin, p.mode) || p.H <= 0 || p.W <= 0 || (p.ldx % 4) || (p.ldo % 8) || !p.x || !p.blocks || !p.out || p.n_chunks < 1 ||
-        (p.mode == PWDW_GATE_MUL && p.n_chunks > 4) || ((p.qT || p.kT) && (!p.qT || !p.kT || p.mode != PWDW_NONE || p.t_chunks < 1 ||
-                                                        3 * p.t_chunks != p.n_chunks || p.t_ld < 64 * p.t_chunks)))
+        (p.mode == PWDW_GATE_MUL && p.n_chunks > 4) || (p.qT && (p.mode != PWDW_NONE || p.t_chunks < 1 || p.t_chunks >= p.n_chunks || p.t_ld < 64 * p.t_chunks)))
         throw Error(1, "pw_dw: shape not eligible");
     dim3 grid((unsigned)pw_dw_blocks(p.H, p.W)), block(512);
 #define FW_F(CG, MODE)                                                                            \

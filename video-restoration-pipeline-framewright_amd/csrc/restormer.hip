@@ -30,6 +30,9 @@ using namespace fw;
 namespace {
 
 int pad_to(int n, int m) { return (n + m - 1) / m * m; }
+// channels per pixel of the fp32 stream (and of every typed operand) at c real channels: whole 32-channel contraction chunks - 48 -> 64,
+// 96 / 192 / 384 as they are (round 2 padded to 64: a third more bytes per pixel at 96 channels, where 20 of the 44 blocks run)
+int stream_pad(int c) { return pad_to(c, 32); }
 
 struct DevBuf {
     void* p = nullptr;
@@ -48,9 +51,9 @@ void upload(DevBuf& b, const void* src, size_t bytes) {
     FW_HIP_CHECK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
 }
 
-// [cout][k] fp32 -> packed pointwise fragments, cout padded to 64 and k to k_pad; returns the number of 32-channel tiles
+// [cout][k] fp32 -> packed pointwise fragments, cout padded to 32 and k to k_pad; returns the number of 32-channel tiles
 int upload_pointwise(DType dt, DevBuf& b, const float* w, int cout, int k, int k_pad) {
-    const int cp = pad_to(cout, 64);
+    const int cp = pad_to(cout, 32);
     std::vector<float> wp((size_t)cp * k_pad, 0.f);
     for (int co = 0; co < cout; ++co)
         for (int i = 0; i < k; ++i) wp[(size_t)co * k_pad + i] = w[(size_t)co * k + i];
@@ -74,7 +77,7 @@ struct Conv3 {
     }
     void build(DType dt, const float* w, int cout, int cin, int cin_pad_or_0) {
         release();
-        cin_pad = cin_pad_or_0 ? cin_pad_or_0 : pad_to(cin, 64);
+        cin_pad = cin_pad_or_0 ? cin_pad_or_0 : stream_pad(cin);
         cout_pad = pad_to(cout, 64);
         std::vector<float> wp((size_t)cout_pad * cin_pad * 9, 0.f);
         for (int co = 0; co < cout; ++co)
@@ -224,7 +227,10 @@ void forward(fw_restormer* n, Arena& A, const uint8_t* d_in, int H, int W, uint8
         const int c = b.c, cp = b.cp, hp = b.hp, heads = b.heads, ch = b.ch;
         const size_t mark = A.top;
         void* t = typ((size_t)M * cp);
-        void* qkv2 = typ((size_t)M * 3 * cp);
+        const int nq = pad_to(3 * cp, 64);          // output channels of the fused qkv kernel: whole 64-channel chunks (q | k | v | zeros)
+        void* qkv2 = typ((size_t)M * nq);
+        const void* v = (const char*)qkv2 + (size_t)2 * cp * 2;   // v as the attention GEMM reads it: [M][v_ld] typed
+        long v_ld = 3 * cp;
         // norm -> 1x1 -> depthwise 3x3 of the 48- / 96-channel blocks: one kernel, the 3c / 5.3c-channel tensor stays in LDS
         auto front = [&](const DevBuf& blocks, int n_out, int mode, void* out, long ldo) {
             PwDwParams f{};
@@ -236,18 +242,23 @@ void forward(fw_restormer* n, Arena& A, const uint8_t* d_in, int H, int W, uint8
         float* aws = f32(fw_attn_workspace_floats(heads, ch));
         if (b.front_qkv.p) {
             // q and k leave the kernel already in the Gram kernel's operand layout (no pixel-major copy of them, no transpose pass)
+            // (q | k: 2 cp channel rows per pixel group = whole chunks at 64 and at 96 channels; v: the chunks behind them, from channel 0 of qkv2)
             const long Mp = pw_dw_transposed_pixels(h, w);
-            void* qT = n->qk_direct ? typ((size_t)Mp * cp) : nullptr;
-            void* kT = n->qk_direct ? typ((size_t)Mp * cp) : nullptr;
+            void* qT = n->qk_direct ? typ((size_t)Mp * 2 * cp) : nullptr;
             PwDwParams f{};
-            f.x = x; f.ldx = cp; f.H = h; f.W = w; f.cin = c; f.ln_eps = 1e-5f; f.blocks = b.front_qkv.p; f.n_chunks = 3 * cp / 64; f.mode = PWDW_NONE;
-            f.out = qkv2; f.ldo = 3 * cp; f.qT = qT; f.kT = kT; f.t_chunks = cp / 64; f.t_ld = cp;
+            f.x = x; f.ldx = cp; f.H = h; f.W = w; f.cin = c; f.ln_eps = 1e-5f; f.blocks = b.front_qkv.p; f.n_chunks = nq / 64; f.mode = PWDW_NONE;
+            f.out = qkv2; f.ldo = n->qk_direct ? nq - 2 * cp : nq; f.qT = qT; f.t_chunks = 2 * cp / 64; f.t_ld = 2 * cp;
             if (run) launch_pw_dw(n->dt, f, st_);
             if (n->qk_direct) {
-                if (run) launch_attn_matrix_from_transposed(n->dt, qT, kT, Mp, cp, heads, ch, (const float*)b.temp.p, aws, attn, st_);
+                v = qkv2;
+                v_ld = nq - 2 * cp;
+                if (run)
+                    launch_attn_matrix_from_transposed(n->dt, qT, (const char*)qT + (size_t)cp * 8 * 2, Mp, 2 * cp, heads, ch, (const float*)b.temp.p, aws, attn,
+                                                       st_);
             } else {
+                v_ld = nq;
                 void* scratch = typ(fw_attn_qk_scratch_elems(M, heads, ch));
-                RUN(fw_attn_matrix_mfma(dt, qkv2, 3 * cp, M, cp, heads, ch, (const float*)b.temp.p, aws, scratch, attn, st));
+                RUN(fw_attn_matrix_mfma(dt, qkv2, nq, M, cp, heads, ch, (const float*)b.temp.p, aws, scratch, attn, st));
             }
         } else {
             RUN(fw_layernorm_nhwc(dt, x, cp, M, c, (const float*)b.n1w.p, (const float*)b.n1b.p, 1e-5f, t, cp, cp, st));
@@ -262,12 +273,10 @@ void forward(fw_restormer* n, Arena& A, const uint8_t* d_in, int H, int W, uint8
         if (n->merge_proj) {
             // x += (project_out . attn) v: the two matrices are multiplied first (c x c x ch MACs), the pixels see one GEMM
             RUN(fw_attn_proj_pack(dt, attn, (const float*)b.proj_f32.p, heads, ch, cp, b.proj_t, apk, st));
-            RUN(fw_pointwise_nhwc(dt, (const char*)qkv2 + (size_t)2 * cp * 2, 0, 3 * cp, M, cp, apk, nullptr, b.proj_t, nullptr, 0, x, cp, x,
-                                  (const float*)n->ones.p, st));
+            RUN(fw_pointwise_nhwc(dt, v, 0, v_ld, M, cp, apk, nullptr, b.proj_t, nullptr, 0, x, cp, x, (const float*)n->ones.p, st));
         } else {
             RUN(fw_attn_pack(dt, attn, heads, ch, cp, apk, st));
-            RUN(fw_pointwise_nhwc(dt, (const char*)qkv2 + (size_t)2 * cp * 2, 0, 3 * cp, M, cp, apk, nullptr, cp / 32, t, cp, nullptr, 0, nullptr,
-                                  nullptr, st));
+            RUN(fw_pointwise_nhwc(dt, v, 0, v_ld, M, cp, apk, nullptr, cp / 32, t, cp, nullptr, 0, nullptr, nullptr, st));
             RUN(fw_pointwise_nhwc(dt, t, 0, cp, M, cp, b.proj.p, nullptr, b.proj_t, nullptr, 0, x, cp, x, (const float*)n->ones.p, st));
         }
         void* g2 = typ((size_t)M * hp);
@@ -286,10 +295,10 @@ void forward(fw_restormer* n, Arena& A, const uint8_t* d_in, int H, int W, uint8
         const Stage& s = n->stages[si];
         for (int i = 0; i < s.n; ++i) block(n->blocks.at(s.name + "." + std::to_string(i) + "."), x, h, w);
     };
-    // conv3x3 (c -> c/2) + PixelUnshuffle(2): fp32 [h*w][pad64(c)] -> fp32 [(h/2)*(w/2)][pad64(2c)]
+    // conv3x3 (c -> c/2) + PixelUnshuffle(2): fp32 [h*w][stream_pad(c)] -> fp32 [(h/2)*(w/2)][stream_pad(2c)]
     auto down = [&](const char* key, const float* x, int h, int w, int c) {
         const Conv3& cv = n->convs.at(key);
-        const size_t ostride = pad_to(2 * c, 64);
+        const size_t ostride = stream_pad(2 * c);
         float* o = f32((size_t)(h / 2) * (w / 2) * ostride);
         zero(o, (size_t)(h / 2) * (w / 2) * ostride * 4);
         const size_t mark = A.top;
@@ -299,10 +308,10 @@ void forward(fw_restormer* n, Arena& A, const uint8_t* d_in, int H, int W, uint8
         A.top = mark;
         return o;
     };
-    // cat([PixelShuffle(2)(conv3x3 (c -> 2c)(x)), skip]): fp32 [(2h)*(2w)][pad64(c)], c/2 + c/2 channels
+    // cat([PixelShuffle(2)(conv3x3 (c -> 2c)(x)), skip]): fp32 [(2h)*(2w)][stream_pad(c)], c/2 + c/2 channels
     auto up_cat = [&](const char* key, const float* x, int h, int w, int c, const float* skip, int skip_stride) {
         const Conv3& cv = n->convs.at(key);
-        const size_t ostride = pad_to(c, 64);
+        const size_t ostride = stream_pad(c);
         float* o = f32((size_t)4 * h * w * ostride);
         zero(o, (size_t)4 * h * w * ostride * 4);
         const size_t mark = A.top;
@@ -334,13 +343,13 @@ void forward(fw_restormer* n, Arena& A, const uint8_t* d_in, int H, int W, uint8
     stage(2, e3, H / 4, W / 4);
     float* lat = down("down3_4.body.0.weight", e3, H / 4, W / 4, 4 * d);
     stage(3, lat, H / 8, W / 8);
-    float* c3 = up_cat("up4_3.body.0.weight", lat, H / 8, W / 8, 8 * d, e3, pad_to(4 * d, 64));
-    float* d3 = reduce(n->red3, n->red3_t, c3, pad_to(8 * d, 64), (long)(H / 4) * (W / 4), 8 * d);
+    float* c3 = up_cat("up4_3.body.0.weight", lat, H / 8, W / 8, 8 * d, e3, stream_pad(4 * d));
+    float* d3 = reduce(n->red3, n->red3_t, c3, stream_pad(8 * d), (long)(H / 4) * (W / 4), 8 * d);
     stage(4, d3, H / 4, W / 4);
-    float* c2 = up_cat("up3_2.body.0.weight", d3, H / 4, W / 4, 4 * d, e2, pad_to(2 * d, 64));
-    float* d2 = reduce(n->red2, n->red2_t, c2, pad_to(4 * d, 64), (long)(H / 2) * (W / 2), 4 * d);
+    float* c2 = up_cat("up3_2.body.0.weight", d3, H / 4, W / 4, 4 * d, e2, stream_pad(2 * d));
+    float* d2 = reduce(n->red2, n->red2_t, c2, stream_pad(4 * d), (long)(H / 2) * (W / 2), 4 * d);
     stage(5, d2, H / 2, W / 2);
-    float* d1 = up_cat("up2_1.body.0.weight", d2, H / 2, W / 2, 2 * d, e1, pad_to(d, 64));
+    float* d1 = up_cat("up2_1.body.0.weight", d2, H / 2, W / 2, 2 * d, e1, stream_pad(d));
     stage(6, d1, H, W);
     stage(7, d1, H, W);
     const Conv3& oc = n->convs.at("output.weight");
@@ -445,7 +454,7 @@ int fw_restormer_finalize(fw_restormer* n) {
         DevGuard dg(n->device);
         const DType dt = n->dt;
         for (const auto& s : n->stages) {
-            const int c = s.c, cp = pad_to(c, 64), hid = (int)(c * n->ffn), hp = pad_to(hid, 32);
+            const int c = s.c, cp = stream_pad(c), hid = (int)(c * n->ffn), hp = pad_to(hid, 32);
             for (int i = 0; i < s.n; ++i) {
                 const std::string p = s.name + "." + std::to_string(i) + ".";
                 RBlock& b = n->blocks[p];
@@ -479,7 +488,13 @@ int fw_restormer_finalize(fw_restormer* n) {
                     pack_pw_dw_blocks(dt, w1.data(), nullptr, H(lnw).data(), H(lnb).data(), dw.data(), nullptr, N, c, gate, pk.data());
                     upload(dst, pk.data(), pk.size());
                 };
-                if (fused) upload_front(b.front_qkv, wqkv, "norm1.body.weight", "norm1.body.bias", wdw, 3 * cp, 0);
+                if (fused) {
+                    const int nq = pad_to(3 * cp, 64);   // whole 64-channel chunks: zero rows behind v at 96 channels (288 -> 320)
+                    std::vector<float> wq_f(wqkv), wdw_f(wdw);
+                    wq_f.resize((size_t)nq * c, 0.f);
+                    wdw_f.resize((size_t)nq * 9, 0.f);
+                    upload_front(b.front_qkv, wq_f, "norm1.body.weight", "norm1.body.bias", wdw_f, nq, 0);
+                }
                 b.proj_t = upload_pointwise(dt, b.proj, H("attn.project_out.weight").data(), c, c, cp);
                 upload(b.proj_f32, H("attn.project_out.weight").data(), (size_t)c * c * 4);
                 // GDFN: x1 rows @ 0, x2 rows @ hp
