@@ -300,4 +300,29 @@ struct Error : std::runtime_error {
         }                                                                                         \
     } while (0)
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// GELU (exact form, 0.5 x (1 + erf(x / sqrt 2))) of two values, erf after Abramowitz & Stegun 7.1.28:
+//   erf(z) = 1 - 1 / (1 + a1 z + ... + a6 z^6)^16,  z >= 0, |error| <= 3e-7 (7e-7 on the GELU in fp32, against scipy on [-12, 12])
+// - one reciprocal, no exponential: Horner and the four squarings run as packed fp32 (v_pk_fma_f32 / v_pk_mul_f32), ~11 issue
+// slots per value where 7.1.26 (a reciprocal AND an exponential, scalar) took ~21.  The depthwise phase of the GDFN kernel is
+// VALU-bound and the gate was 60 % of it.  Large |x|: the power overflows to inf, 1 / inf = 0, erf = 1.
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+    const f32x2 ax = {__builtin_fabsf(x[0]), __builtin_fabsf(x[1])};
+    const f32x2 z = ax * 0.70710678118654752f;
+    f32x2 q = z * 0.0000430638f + 0.0002765672f;
+    q = q * z + 0.0001520143f;
+    q = q * z + 0.0092705272f;
+    q = q * z + 0.0422820123f;
+    q = q * z + 0.0705230784f;
+    q = q * z + 1.0f;
+    q = q * q;
+    q = q * q;
+    q = q * q;
+    q = q * q;
+    const f32x2 r = {__builtin_amdgcn_rcpf(q[0]), __builtin_amdgcn_rcpf(q[1])};
+    const f32x2 h = ax * 0.5f;          // 0.5 (x + |x| erf) = (0.5 x + 0.5 |x|) - 0.5 |x| r
+    const f32x2 s = x * 0.5f + h;
+    return s - h * r;
+}
+
 }  // namespace fw

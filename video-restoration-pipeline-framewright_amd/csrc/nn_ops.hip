@@ -73,8 +73,9 @@ constexpr int PW_PX = 256;
 
 template <typename T, int CT, int MODE>
 __global__ __launch_bounds__(256, 2) void pointwise_mfma_kernel(const PointwiseParams p) {
-    __shared__ __attribute__((aligned(16))) uint4 lds_a[PW_PX * 4];
-    __shared__ __attribute__((aligned(16))) uint4 lds_w[2 * CT * 64];
+    __shared__ __attribute__((aligned(16))) uint4 lds_all[PW_PX * 4 + 2 * CT * 64];   // one array: the residual epilogue reuses all of it
+    uint4* const lds_a = lds_all;
+    uint4* const lds_w = lds_all + PW_PX * 4;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int n_tiles = (p.N_tiles + CT - 1) / CT;  // blocks along couts
@@ -243,6 +244,62 @@ __global__ __launch_bounds__(256, 2) void pointwise_mfma_kernel(const PointwiseP
     }
 
     // ---- epilogue: lane holds pixel (wave*64 + pt*32 + r), couts 32*tile + 8g + 4h + j ------------------------------
+#ifndef FW_PW_RES_DIRECT
+    if constexpr (MODE == PW_RESIDUAL) {
+        // The residual epilogue moves four times the bytes of the K loop at K = N (fp32 stream in and out against a typed operand),
+        // and straight from the accumulator layout a wave-instruction touched 32 pixel rows with 32 bytes each.  Here each 32-pixel
+        // x 32-channel accumulator tile is turned round in a wave-private LDS slice ([32][36] floats in the staging buffers the K
+        // loop is done with; conflict-free 16-byte writes), after which 8 lanes own one pixel's 128 contiguous bytes: the stream is
+        // read and written in whole cache lines.  The reads of a 32-pixel group are issued before its tiles are turned.
+        __syncthreads();                                            // every wave is done with lds_a / lds_w
+        static_assert((PW_PX * 4 + 2 * CT * 64) * 16 >= 4 * 32 * 36 * 4, "staging buffers too small for the epilogue slices");
+        float* slice = reinterpret_cast<float*>(lds_all) + wave * (32 * 36);
+        const int piece = lane & 7, prow = lane >> 3;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const long mg = m0 + wave * 64 + pt * 32;                 // first pixel of the group (wave-uniform)
+            if (mg >= p.M) continue;
+            f32x4 rs[CT][4];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int tile = bn * CT + ct;
+                if (tile >= p.N_tiles) continue;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const long m = mg + prow + 8 * i;
+                    rs[ct][i] = m < p.M ? *reinterpret_cast<const f32x4*>(p.res_f32 + m * p.ldf + 32 * tile + 4 * piece) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int tile = bn * CT + ct;
+                if (tile >= p.N_tiles) continue;
+                const int n = 32 * tile + 4 * piece;
+                const f32x4 bs = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(p.chan_scale + n);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {acc[pt][ct][4 * g], acc[pt][ct][4 * g + 1], acc[pt][ct][4 * g + 2], acc[pt][ct][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(slice + r * 36 + 8 * g + 4 * h) = v;
+                }
+                // (a wave reads back only what it wrote: no workgroup barrier; the compiler orders the LDS accesses of one wave)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const long m = mg + prow + 8 * i;
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(slice + (prow + 8 * i) * 36 + 4 * piece);
+                    f32x4 of;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float o = a[j] + bs[j];
+                        of[j] = rs[ct][i][j] + o * sc[j];
+                    }
+                    if (m < p.M) *reinterpret_cast<f32x4*>(p.out_f32 + m * p.ldf + n) = of;
+                }
+            }
+        }
+        return;
+    }
+#endif
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
         const long m = m0 + wave * 64 + pt * 32 + r;

@@ -37,22 +37,6 @@ constexpr int FR_TAIL = 11 * 64 * 4;                  // per chunk: depthwise ta
 
 constexpr int pw_dw_block_bytes(int kc) { return (kc * 4096 + FR_TAIL + 1023) / 1024 * 1024; }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// erf after Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7): the GDFN gate's exact GELU at a third of erff's instructions
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float ax = __builtin_fabsf(x);
-    const float z = ax * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
-    float q = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-    q = __builtin_fmaf(q, t, 1.421413741f);
-    q = __builtin_fmaf(q, t, -0.284496736f);
-    q = __builtin_fmaf(q, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
-    const float erf_abs = __builtin_fmaf(-q * t, e, 1.0f);
-    // 0.5 x (1 + erf(x / sqrt 2)) = 0.5 (x + |x| erf(|x| / sqrt 2))
-    return 0.5f * __builtin_fmaf(ax, erf_abs, x);
-}
 
 // CG: 16-channel groups of the input (c = 16 CG); MODE: PWDW_NONE / PWDW_GATE_MUL / PWDW_GATE_GELU
 template <typename T, int CG, int MODE>
@@ -274,8 +258,8 @@ __global__ __launch_bounds__(512, 2) void pw_dw_kernel(const PwDwParams p) {
 #pragma unroll
                     for (int o = 0; o < FR_STRIP; ++o) {
                         if constexpr (MODE == PWDW_GATE_GELU) {
-                            x1a[o] = f32x2{gelu_erf(aa[o][0]), gelu_erf(aa[o][1])};
-                            x1b[o] = f32x2{gelu_erf(ab[o][0]), gelu_erf(ab[o][1])};
+                            x1a[o] = gelu_erf2(aa[o]);
+                            x1b[o] = gelu_erf2(ab[o]);
                         } else {
                             x1a[o] = aa[o];
                             x1b[o] = ab[o];
