@@ -108,6 +108,46 @@ def test_attention_matrix_and_apply(hip_lib, dtype, heads, ch, M):
     assert (got2[:, dim:] == 0).all()
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("M,K,N,lda,ld", [(777, 96, 96, 128, 96), (4096, 1024, 384, 1024, 384), (5000, 384, 1152, 384, 1152), (300, 192, 192, 576, 192),
+                                          (20000, 96, 96, 128, 96), (17000, 256, 96, 256, 96), (16500, 64, 64, 192, 64), (16400, 192, 576, 192, 576)])
+def test_pointwise_1x1_typed_store_and_residual(hip_lib, dtype, M, K, N, lda, ld):
+    """fw_pointwise_nhwc on a typed operand: the few-pixel kernel (M <= 16384: pointwise_small_kernel, nn_ops.hip) and the large one, typed
+    store and fp32 residual epilogue (the stream updated in place), against torch fp32 on the operand-rounded inputs; lanes behind N untouched."""
+    g = torch.Generator().manual_seed(M + K + N)
+    dt = _lib.DTYPES[dtype]
+    a = torch.zeros(M, lda)
+    a[:, :K] = torch.randn(M, K, generator=g)
+    a = a.to(TDT[dtype])
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    Np = (N + 31) // 32 * 32
+    wp = np.zeros((Np, K), np.float32)
+    wp[:N] = w.numpy()
+    n16 = int(hip_lib.fw_pack_pointwise(dt, None, Np, K, None))
+    pk = np.zeros(n16, np.uint16)
+    assert int(hip_lib.fw_pack_pointwise(dt, wp.ctypes.data_as(C.c_void_p), Np, K, pk.ctypes.data_as(C.c_void_p))) == n16
+    pkd, ad = torch.from_numpy(pk.view(np.int16)).cuda(), a.cuda()
+    want = a[:, :K].float() @ w.to(TDT[dtype]).float().T
+    scale_ref = max(1.0, want.abs().max().item())
+    tol = 2e-3 if dtype == "f16" else 1.6e-2
+    # typed store
+    out = torch.full((M, ld + 8), 7.0, dtype=TDT[dtype], device="cuda")
+    _lib.check(hip_lib.fw_pointwise_nhwc(dt, P(ad), 0, lda, M, K, P(pkd), None, Np // 32, P(out), ld + 8, None, 0, None, None, _st()))
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    assert (got[:, :N] - want).abs().max() < tol * scale_ref
+    assert (got[:, Np:] == 7.0).all()
+    # residual: x += y * scale, fp32 stream in place
+    x = torch.randn(M, ld, generator=g)
+    sc = 0.5 + torch.rand(Np, generator=g)
+    xd, sd = x.clone().cuda(), sc.cuda()
+    if Np <= ld:
+        _lib.check(hip_lib.fw_pointwise_nhwc(dt, P(ad), 0, lda, M, K, P(pkd), None, Np // 32, None, 0, P(xd), ld, P(xd), P(sd), _st()))
+        torch.cuda.synchronize()
+        got = xd.cpu()
+        assert (got[:, :N] - (x[:, :N] + want * sc[:N])).abs().max() < 2e-5 * scale_ref + 1e-5   # fp32 accumulate and epilogue: only the sum order differs
+
+
 def test_pixel_shuffle_and_unshuffle(hip_lib):
     g = torch.Generator().manual_seed(3)
     h, w, c = 5, 7, 6

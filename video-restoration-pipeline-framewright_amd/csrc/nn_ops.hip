@@ -136,10 +136,10 @@ __global__ __launch_bounds__(256, 2) void pointwise_mfma_kernel(const PointwiseP
             ln_rstd[i] = 1.0f / sqrtf(qq * (1.f / 64.f) + p.ln_eps);
         }
     }
-    auto consume = [&](int c, const uint4 (&v)[4]) {
-        uint4 wv[(2 * CT * 64 + 255) / 256];
+    constexpr int NWV = (2 * CT * 64 + 255) / 256;
+    auto wload = [&](int c, uint4 (&wv)[NWV]) {
 #pragma unroll
-        for (int i = 0; i < (2 * CT * 64 + 255) / 256; ++i) {
+        for (int i = 0; i < NWV; ++i) {
             const int idx = tid + 256 * i;
             if (idx < 2 * CT * 64) {
                 // fragment order [chunk][ks][cout tile][lane]; this block's cout tiles start at bn*CT (MODE gate: see below)
@@ -152,6 +152,8 @@ __global__ __launch_bounds__(256, 2) void pointwise_mfma_kernel(const PointwiseP
                             : make_uint4(0, 0, 0, 0);
             }
         }
+    };
+    auto stage = [&](const uint4 (&v)[4], const uint4 (&wv)[NWV]) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -160,11 +162,13 @@ __global__ __launch_bounds__(256, 2) void pointwise_mfma_kernel(const PointwiseP
             lds_a[px * 4 + (s ^ ((px >> 2) & 3))] = v[i];
         }
 #pragma unroll
-        for (int i = 0; i < (2 * CT * 64 + 255) / 256; ++i) {
+        for (int i = 0; i < NWV; ++i) {
             const int idx = tid + 256 * i;
             if (idx < 2 * CT * 64) lds_w[idx] = wv[i];
         }
         __syncthreads();
+    };
+    auto mma = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             uint4 wf[CT];
@@ -191,11 +195,16 @@ __global__ __launch_bounds__(256, 2) void pointwise_mfma_kernel(const PointwiseP
                 for (int j = 0; j < 8; ++j) f[j] = (lnv[i][c][j] - ln_mean[i]) * ln_rstd[i] * p.ln_w[kk + j] + p.ln_b[kk + j];
                 v[i] = (m0 + ((tid + 256 * i) >> 2) < p.M) ? pack8f<T>(f) : make_uint4(0, 0, 0, 0);
             }
-            consume(c, v);
+            uint4 wv[NWV];
+            wload(c, wv);
+            stage(v, wv);
+            mma();
         }
     }
-    for (int c = 0; c < (ln ? 0 : chunks); ++c) {
-        uint4 v[4];
+    // The other inputs: chunk c + 1's loads (operand rows and weight fragments) are issued right after chunk c is staged, so they are
+    // in flight while its MFMAs run (they used to be issued after them: load latency + MFMAs per chunk, exposed whenever a CU holds
+    // one workgroup - the 16 k- and 4 k-pixel levels of Restormer, NAFNet's deep levels).
+    auto aload = [&](int c, uint4 (&v)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + 256 * i;
@@ -240,7 +249,19 @@ __global__ __launch_bounds__(256, 2) void pointwise_mfma_kernel(const PointwiseP
                 }
             }
         }
-        consume(c, v);
+    };
+    if (!ln) {
+        uint4 v[4], wv[NWV];
+        aload(0, v);
+        wload(0, wv);
+        for (int c = 0; c < chunks; ++c) {
+            stage(v, wv);
+            if (c + 1 < chunks) {
+                aload(c + 1, v);
+                wload(c + 1, wv);
+            }
+            mma();
+        }
     }
 
     // ---- epilogue: lane holds pixel (wave*64 + pt*32 + r), couts 32*tile + 8g + 4h + j ------------------------------
@@ -398,6 +419,179 @@ __global__ __launch_bounds__(256, 2) void pointwise_mfma_kernel(const PointwiseP
     }
 }
 
+// =====================================================================================================
+// The same GEMM for FEW pixels (Restormer's 192- / 384-channel levels of a 512 x 512 tile: 16 k / 4 k pixels, K up to 1024).
+// The kernel above gives such a launch 16 - 64 workgroups for 256 CUs, each walking K in 32-channel chunks with one exposed load
+// latency and two barriers per chunk (27 / 55 us at 4096 pixels, K = 384 / 1024).  Here
+//   * a workgroup owns 64 pixels x 128 output channels and its four waves split the OUTPUT CHANNELS (wave w: cout tile 4 bn + w,
+//     both 32-pixel groups): four times the workgroups, and a wave's weight fragments are its own - they go from global memory
+//     straight into registers (1 KiB per wave-instruction, no LDS);
+//   * K is walked in stages of 8 chunks (256 channels): a pixel's 512 contiguous bytes are loaded by 32 lanes, staged through LDS
+//     in the swizzled image of the kernel above, and the next stage's loads (A and weights: 24 x 16 bytes per lane) are in flight
+//     while the 32 MFMAs of this stage run: K = 1024 costs 4 load latencies, not 32;
+//   * epilogues: the typed 16-byte store and the turned residual epilogue of the kernel above, per wave.
+// Typed operand A only (no fp32 / gather / SCA scale / fused LayerNorm): launch_pointwise routes the rest to the kernel above.
+// =====================================================================================================
+constexpr int PWS_NS = 8;      // chunks per stage
+constexpr int PWS_PX = 64;     // pixels per workgroup
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void pointwise_small_kernel(const PointwiseParams p) {
+    __shared__ __attribute__((aligned(16))) uint4 lds_a[PWS_NS * PWS_PX * 4];   // [chunk][pixel][4 slots], 32 KiB
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int n_blocks = (p.N_tiles + 3) / 4;
+    const int bm = blockIdx.x / n_blocks, bn = blockIdx.x - bm * n_blocks;
+    const long m0 = (long)bm * PWS_PX;
+    const int tile = bn * 4 + wave;
+    const bool live = tile < p.N_tiles;      // wave-uniform: a wave without a tile still stages A and meets the barriers
+    const int chunks = p.K / 32, stages = (chunks + PWS_NS - 1) / PWS_NS;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[pt][i] = 0.f;
+
+    uint4 av[8], wv[PWS_NS][2];
+    auto fetch = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {        // slot idx = tid + 256 i: pixel idx >> 5, 16-byte slot idx & 31 of the stage's 512 bytes
+            const int idx = tid + 256 * i, px = idx >> 5, sl = idx & 31;
+            const long m = m0 + px;
+            const int kk = (s * PWS_NS) * 32 + sl * 8;
+            av[i] = (m < p.M && kk < p.K) ? *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.a) + m * p.lda + kk) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < PWS_NS; ++c)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int cg = s * PWS_NS + c;
+                wv[c][ks] = (live && cg < chunks) ? reinterpret_cast<const uint4*>(p.wpk)[(((size_t)cg * 2 + ks) * p.N_tiles + tile) * 64 + lane]
+                                                  : make_uint4(0, 0, 0, 0);
+            }
+    };
+    fetch(0);
+    for (int s = 0; s < stages; ++s) {
+        __syncthreads();                      // the previous stage's fragments are read
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i, px = idx >> 5, sl = idx & 31, c = sl >> 2, s4 = sl & 3;
+            lds_a[(c * PWS_PX + px) * 4 + (s4 ^ ((px >> 2) & 3))] = av[i];
+        }
+        uint4 wf[PWS_NS][2];
+#pragma unroll
+        for (int c = 0; c < PWS_NS; ++c)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) wf[c][ks] = wv[c][ks];
+        __syncthreads();
+        if (s + 1 < stages) fetch(s + 1);     // in flight while this stage's MFMAs run
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < PWS_NS; ++c)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt) {
+                        const int px = pt * 32 + r;
+                        const uint4 xf = lds_a[(c * PWS_PX + px) * 4 + ((2 * ks + h) ^ ((px >> 2) & 3))];
+                        acc[pt] = Tr<T>::mfma(wf[c][ks], xf, acc[pt]);
+                    }
+        }
+    }
+    if constexpr (MODE == PW_RESIDUAL) {
+        // the turned epilogue of pointwise_mfma_kernel: a [32][36]-float slice per wave in the staging image (free once every wave is
+        // past its last MFMA: one barrier, reached by the waves without a tile as well), 8 lanes own a pixel's 128 bytes
+        __syncthreads();
+        if (!live) return;
+        float* slice = reinterpret_cast<float*>(lds_a) + wave * (32 * 36);
+        const int piece = lane & 7, prow = lane >> 3;
+        const int n = 32 * tile + 4 * piece;
+        const f32x4 bs = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.chan_scale + n);
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const long mg = m0 + pt * 32;
+            if (mg >= p.M) continue;
+            f32x4 rs[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long m = mg + prow + 8 * i;
+                rs[i] = m < p.M ? *reinterpret_cast<const f32x4*>(p.res_f32 + m * p.ldf + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc[pt][4 * g], acc[pt][4 * g + 1], acc[pt][4 * g + 2], acc[pt][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(slice + r * 36 + 8 * g + 4 * h) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long m = mg + prow + 8 * i;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(slice + (prow + 8 * i) * 36 + 4 * piece);
+                f32x4 of;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float o = a[j] + bs[j];
+                    of[j] = rs[i][j] + o * sc[j];
+                }
+                if (m < p.M) *reinterpret_cast<f32x4*>(p.out_f32 + m * p.ldf + n) = of;
+            }
+        }
+    } else {
+        if (!live) return;
+        // typed output, 16 bytes per lane (v_permlane32_swap pairs the fragments of channel groups g, g + 1: see PW_STORE above)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const long m = m0 + pt * 32 + r;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                uint2 pk[2];
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg) {
+                    const int g = 2 * gp + gg;
+                    const int n = 32 * tile + 8 * g + 4 * h;
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = acc[pt][4 * g + j] + (p.bias ? p.bias[n + j] : 0.f);
+                    pk[gg] = pack4f<T>(o[0], o[1], o[2], o[3]);
+                }
+                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                const u32x2_t sx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+                const u32x2_t sy = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+                *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out_typed) + m * p.ldo + 32 * tile + 16 * gp + 8 * h) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            }
+        }
+    }
+}
+
+// few pixels, a typed operand and nothing fused into the staging: the kernel above (FW_PW_SMALL_MAX_M=0 turns it off for A/B)
+static bool pointwise_small_eligible(const PointwiseParams& p) {
+    static const long max_m = [] {
+        const char* e = getenv("FW_PW_SMALL_MAX_M");
+        return e ? atol(e) : 16384L;
+    }();
+    if (p.M > max_m || p.a_f32 || p.gather2x2 || p.a_scale || p.ln_w || (p.lda & 7) || ((size_t)p.a & 15)) return false;
+    // Many output channels: every 64-pixel workgroup column streams all of W again (N = 1152 / 2048 at 4096 pixels: 21.6 / 28.5 us here
+    // against 23.4 / 25.5 in the 256-pixel kernel; N = 576 / 1024 at 16 k pixels: 23.6 / 37.2 against 17.7 / 22.1) - the kernel is for
+    // N <= 384, which is every residual GEMM of the two levels (9.4 - 21.6 us against 21 - 55)
+    if (p.N_tiles > 12) return false;
+    if (p.mode == PW_RESIDUAL) return p.out_f32 && p.res_f32 && p.chan_scale && !(p.ldf & 3);
+    return p.mode == PW_STORE && p.out_typed && !p.out_f32 && !(p.ldo & 7);
+}
+
+template <typename T>
+static void launch_pw_small(const PointwiseParams& p, hipStream_t st) {
+    const long mb = (p.M + PWS_PX - 1) / PWS_PX;
+    const dim3 grid((unsigned)(mb * ((p.N_tiles + 3) / 4)));
+    if (p.mode == PW_RESIDUAL)
+        hipLaunchKernelGGL((pointwise_small_kernel<T, PW_RESIDUAL>), grid, dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((pointwise_small_kernel<T, PW_STORE>), grid, dim3(256), 0, st, p);
+    FW_HIP_CHECK(hipGetLastError());
+}
+
+
 template <typename T>
 static void launch_pw_typed(const PointwiseParams& p, hipStream_t st) {
     const long mb = (p.M + PW_PX - 1) / PW_PX;
@@ -443,6 +637,10 @@ void launch_pointwise(DType dt, const PointwiseParams& p, hipStream_t st) {
     if (p.gather2x2 && (p.Cin & 31)) throw Error(1, "pointwise: 2x2 gather needs Cin % 32 == 0");
     if (p.ln_w && (!p.ln_b || !p.a_f32 || p.gather2x2 || p.a_scale || p.K != 64 || p.lda != 64))
         throw Error(1, "pointwise: fused LayerNorm needs a plain fp32 [M][64] input");
+    if (pointwise_small_eligible(p)) {
+        if (dt == DT_BF16) launch_pw_small<__bf16>(p, st); else launch_pw_small<_Float16>(p, st);
+        return;
+    }
     if (dt == DT_BF16)
         launch_pw_typed<__bf16>(p, st);
     else
