@@ -574,7 +574,8 @@ static bool pointwise_small_eligible(const PointwiseParams& p) {
     if (p.M > max_m || p.a_f32 || p.gather2x2 || p.a_scale || p.ln_w || (p.lda & 7) || ((size_t)p.a & 15)) return false;
     // Many output channels: every 64-pixel workgroup column streams all of W again (N = 1152 / 2048 at 4096 pixels: 21.6 / 28.5 us here
     // against 23.4 / 25.5 in the 256-pixel kernel; N = 576 / 1024 at 16 k pixels: 23.6 / 37.2 against 17.7 / 22.1) - the kernel is for
-    // N <= 384, which is every residual GEMM of the two levels (9.4 - 21.6 us against 21 - 55)
+    // N <= 384, which is every residual GEMM of the two levels (9.4 - 21.6 us against 21 - 55).  A 128-pixel form of it (half the weight
+    // stream per pixel, 415 registers) for qkv / project_in was slower than the 256-pixel kernel as well: 10.53 against 10.33 ms per tile.
     if (p.N_tiles > 12) return false;
     if (p.mode == PW_RESIDUAL) return p.out_f32 && p.res_f32 && p.chan_scale && !(p.ldf & 3);
     return p.mode == PW_STORE && p.out_typed && !p.out_f32 && !(p.ldo & 7);
