@@ -240,3 +240,27 @@ def test_pairs_in_flight_on_streams_equal_one_at_a_time(hip_lib):
     torch.cuda.synchronize()
     assert torch.equal(one[0], want[0])
     eng.close()
+
+
+@pytest.mark.parametrize("H,W,gain,tol", [(70, 100, 1.0, 2e-4), (270, 480, 1.0, 2e-4), (270, 480, 12.0, 2e-3)])
+def test_fused_block_input_and_accumulate_equal_the_separate_kernels(hip_lib, monkeypatch, H, W, gain, tol):
+    """An IFBlock's input as one kernel (build_x + both resizes + cat + pixel_unshuffle + cast) and lastconv's depth-to-space inside the
+    accumulate evaluate the same expressions as the separate kernels (FW_IFNET_FUSE_GLUE=0): the fp32 frames agree to the rounding noise of
+    the compiler's FMA contraction (a last-bit difference in X flips f16 roundings of the conv input; with 12 x larger flows the four blocks
+    amplify that to 6e-4), the uint8 frames to 1 LSB at most."""
+    sd = synthetic_ifnet_state(seed=99, flow_gain=gain)
+    fr = synthetic_frames(2, H, W, seed=W)
+    a, b = torch.from_numpy(fr[0]).cuda(), torch.from_numpy(fr[1]).cuda()
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FW_IFNET_FUSE_GLUE", flag)
+        eng = RF.IFNetEngine("f16")
+        eng.load_state_dict(sd)
+        rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        u8 = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+        eng.interpolate_device(a, b, 0.5, out=u8, out_rgb_f32=rgb)
+        torch.cuda.synchronize()
+        res[flag] = (rgb.cpu().numpy(), u8.cpu().numpy().astype(int))
+        eng.close()
+    assert np.abs(res["1"][0] - res["0"][0]).max() < tol
+    assert np.abs(res["1"][1] - res["0"][1]).max() <= 1

@@ -271,6 +271,10 @@ void launch_ifnet_build_x(const float* i0, const float* i1, const float* flow, c
 void launch_unshuffle2_cast(DType dt, const void* src, bool src_f32, int h, int w, int C, int src_cstride, void* dst,
                             int dst_channels, hipStream_t st);
 void launch_depth_to_space4(const float* src, int h, int w, int cs, float* dst, hipStream_t st);
+// build_x + both resizes + cat + pixel_unshuffle(2) + cast of an IFBlock's input in one kernel; lastconv's depth-to-space inside the accumulate
+void launch_ifnet_stage_input(DType dt, const float* i0, const float* i1, const float* flow, const float* mask, int H, int W, float timestep,
+                              int s, void* dst, int dst_channels, hipStream_t st);
+void launch_ifnet_accumulate_d2s(const float* t96, int hf, int wf, int cs, int H, int W, float scale, float* flow, float* mask, int first, hipStream_t st);
 void launch_ifnet_accumulate(const float* tmp, int hs, int ws, int H, int W, float scale, float* flow, float* mask, int first,
                              hipStream_t st);
 void launch_ifnet_blend(const float* i0, const float* i1, const float* flow, const float* mask, int Hp, int Wp, int H, int W,

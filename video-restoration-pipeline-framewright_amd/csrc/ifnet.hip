@@ -169,6 +169,7 @@ struct fw_ifnet {
     // a caller that hands over fresh buffers every frame would re-capture every frame)
     int graph_mode = 0;
     bool merge_groups = true;   // the 64-channel output groups of a conv in one launch (FW_IFNET_MERGE_GROUPS=0: A/B)
+    bool fuse_glue = true;      // an IFBlock's input in one kernel, depth-to-space inside the accumulate (FW_IFNET_FUSE_GLUE=0: A/B)
     bool warmed = false;
     struct GraphEntry {
         int H, W;
@@ -307,10 +308,14 @@ void forward(fw_ifnet* n, const uint8_t* d0, const uint8_t* d1, int H, int W, fl
         const Block& b = n->blk[i];
         const bool first = i == 0;
         const int s = SC[i], hs = Hp / s, wsz = Wp / s;
-        launch_ifnet_build_x(I0, I1, first ? nullptr : flow, first ? nullptr : mask, Hp, Wp, timestep, X, st);
-        launch_resize_bilinear(X, Hp, Wp, first ? 7 : 8, xin, hs, wsz, b.cin, 0, 1.0f / s, 1.0f, st);
-        if (!first) launch_resize_bilinear(flow, Hp, Wp, 4, xin, hs, wsz, b.cin, 8, 1.0f / s, 1.0f / s, st);
-        launch_unshuffle2_cast(n->dt, xin, true, hs, wsz, b.cin, b.cin, u0, b.conv00.cin_pad, st);
+        if (n->fuse_glue) {
+            launch_ifnet_stage_input(n->dt, I0, I1, first ? nullptr : flow, first ? nullptr : mask, Hp, Wp, timestep, s, u0, b.conv00.cin_pad, st);
+        } else {
+            launch_ifnet_build_x(I0, I1, first ? nullptr : flow, first ? nullptr : mask, Hp, Wp, timestep, X, st);
+            launch_resize_bilinear(X, Hp, Wp, first ? 7 : 8, xin, hs, wsz, b.cin, 0, 1.0f / s, 1.0f, st);
+            if (!first) launch_resize_bilinear(flow, Hp, Wp, 4, xin, hs, wsz, b.cin, 8, 1.0f / s, 1.0f / s, st);
+            launch_unshuffle2_cast(n->dt, xin, true, hs, wsz, b.cin, b.cin, u0, b.conv00.cin_pad, st);
+        }
         run_conv(n, b.conv00, u0, hs / 2, wsz / 2, a0, nullptr, 1, nullptr, nullptr, 0, st);
         launch_unshuffle2_cast(n->dt, a0, false, hs / 2, wsz / 2, b.c2p, b.c2p, u1, b.conv01.cin_pad, st);
         const int hf = hs / 4, wf = wsz / 4;
@@ -323,8 +328,12 @@ void forward(fw_ifnet* n, const uint8_t* d0, const uint8_t* d1, int H, int W, fl
             std::swap(feat32, nxt32);
         }
         run_conv(n, b.last, feat, hf, wf, nullptr, t96, 0, nullptr, nullptr, 0, st);
-        launch_depth_to_space4(t96, hf, wf, 96, tmp, st);
-        launch_ifnet_accumulate(tmp, hs, wsz, Hp, Wp, (float)s, flow, mask, first ? 1 : 0, st);
+        if (n->fuse_glue) {
+            launch_ifnet_accumulate_d2s(t96, hf, wf, 96, Hp, Wp, (float)s, flow, mask, first ? 1 : 0, st);
+        } else {
+            launch_depth_to_space4(t96, hf, wf, 96, tmp, st);
+            launch_ifnet_accumulate(tmp, hs, wsz, Hp, Wp, (float)s, flow, mask, first ? 1 : 0, st);
+        }
     }
     launch_ifnet_blend(I0, I1, flow, mask, Hp, Wp, H, W, d_out, d_rgb, st);
     FW_HIP_CHECK(hipGetLastError());
@@ -360,6 +369,7 @@ int fw_ifnet_create(int device_id, int dtype, fw_ifnet** out) {
         n->dt = (DType)dtype;
         if (const char* e = getenv("FW_IFNET_GRAPH")) n->graph_mode = atoi(e);
         if (const char* e = getenv("FW_IFNET_MERGE_GROUPS")) n->merge_groups = atoi(e) != 0;
+        if (const char* e = getenv("FW_IFNET_FUSE_GLUE")) n->fuse_glue = atoi(e) != 0;
         for (int i = 0; i < NBLK; ++i) {
             Block& b = n->blk[i];
             b.c = CH[i];

@@ -176,6 +176,109 @@ __global__ __launch_bounds__(256) void ifnet_accumulate_kernel(const float* __re
     }
 }
 
+// The front of an IFBlock as ONE kernel: build_x -> F.interpolate(x, 1 / s) -> F.interpolate(flow, 1 / s) / s -> cat -> pixel_unshuffle(2)
+// -> operand type.  The four kernels above wrote and re-read the 8-channel X at full resolution for every block (at 1080p: 200 of the
+// 1820 us of a forward in the last block alone, half of it an identity resize at s = 1).  Here a thread owns one pixel of the RESIZED map
+// (4 threads = one pixel of the unshuffled output), evaluates X and the flow only at the full-resolution taps that pixel samples (at
+// s = 8 that is 4 of 64 positions) with the SAME expressions in the same order as those kernels (a tap whose weight is exactly 0 is
+// skipped: p * 1 + q * 0 = p), and a workgroup's 64 output pixels leave through an LDS tile as contiguous 16-byte pieces (channel
+// c * 4 + dy * 2 + dx, zeros behind 4 cin).
+struct IfnX {
+    float v[12];
+};
+template <int CIN>
+__device__ __forceinline__ IfnX ifnet_x_at(const float* __restrict__ i0, const float* __restrict__ i1, const float* __restrict__ flow,
+                                           const float* __restrict__ mask, int H, int W, float timestep, int yy, int xx) {
+    IfnX r;
+    const size_t ip = (size_t)yy * W + xx;
+    if constexpr (CIN == 12) {
+        const float4 f = *reinterpret_cast<const float4*>(flow + ip * 4);
+        warp_px(i0, H, W, xx + f.x, yy + f.y, r.v);
+        warp_px(i1, H, W, xx + f.z, yy + f.w, r.v + 3);
+        r.v[6] = timestep;
+        r.v[7] = mask[ip];
+        r.v[8] = f.x, r.v[9] = f.y, r.v[10] = f.z, r.v[11] = f.w;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            r.v[c] = i0[ip * 3 + c];
+            r.v[3 + c] = i1[ip * 3 + c];
+        }
+        r.v[6] = timestep;
+#pragma unroll
+        for (int c = 7; c < 12; ++c) r.v[c] = 0.f;
+    }
+    return r;
+}
+
+template <typename T, int CIN>
+__global__ __launch_bounds__(256) void ifnet_stage_input_kernel(const float* __restrict__ i0, const float* __restrict__ i1,
+                                                                const float* __restrict__ flow, const float* __restrict__ mask, int H, int W,
+                                                                float timestep, float inv_sf, float fmul, int hs, int ws, T* dst, int Cpad) {
+    __shared__ __attribute__((aligned(16))) T tile[64 * 64];   // [pixel of the unshuffled map][Cpad <= 64]
+    constexpr int CX = CIN == 12 ? 8 : 7;
+    const int wo = ws / 2;
+    const long n = (long)(hs / 2) * wo;
+    const int pl = threadIdx.x >> 2, sub = threadIdx.x & 3;
+    for (long base = (long)blockIdx.x * 64; base < n; base += (long)gridDim.x * 64) {   // uniform: barriers inside
+        reinterpret_cast<uint4*>(tile)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+        reinterpret_cast<uint4*>(tile)[threadIdx.x + 256] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        const long i = base + pl;
+        if (i < n) {
+            const int yo = (int)(i / wo), xo = (int)(i - (long)yo * wo);
+            const int y = 2 * yo + (sub >> 1), x = 2 * xo + (sub & 1);
+            int y0, y1, x0, x1;
+            float wy, wx;
+            bilin_setup(y, inv_sf, H, &y0, &y1, &wy);
+            bilin_setup(x, inv_sf, W, &x0, &x1, &wx);
+            const bool hx = wx != 0.f, hy = wy != 0.f;
+            const IfnX a00 = ifnet_x_at<CIN>(i0, i1, flow, mask, H, W, timestep, y0, x0);
+            const IfnX a01 = hx ? ifnet_x_at<CIN>(i0, i1, flow, mask, H, W, timestep, y0, x1) : a00;
+            const IfnX a10 = hy ? ifnet_x_at<CIN>(i0, i1, flow, mask, H, W, timestep, y1, x0) : a00;
+            const IfnX a11 = (hx && hy) ? ifnet_x_at<CIN>(i0, i1, flow, mask, H, W, timestep, y1, x1) : (hx ? a01 : a10);
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                const float top = a00.v[c] * (1.f - wx) + a01.v[c] * wx;
+                const float bot = a10.v[c] * (1.f - wx) + a11.v[c] * wx;
+                tile[pl * Cpad + c * 4 + sub] = cvt<T>((top * (1.f - wy) + bot * wy) * (c < CX ? 1.0f : fmul));
+            }
+        }
+        __syncthreads();
+        const int ppp = Cpad / 8;                               // 16-byte pieces per pixel
+        for (int k = threadIdx.x; k < 64 * ppp; k += 256)
+            if (base + k / ppp < n) *reinterpret_cast<uint4*>(dst + base * Cpad + (long)k * 8) = reinterpret_cast<const uint4*>(tile)[k];
+        __syncthreads();
+    }
+}
+
+// ifnet_accumulate_kernel reading lastconv's output in place: tmp[Y][X][c6] = src[(Y >> 2, X >> 2)][((c6 * 4 + (Y & 1) * 2 + (X & 1)) * 4
+// + ((Y >> 1) & 1) * 2 + ((X >> 1) & 1))] (depth_to_space4_kernel's permutation), so the [4h][4w][6] copy is never written.
+__global__ __launch_bounds__(256) void ifnet_accumulate_d2s_kernel(const float* __restrict__ t96, int hf, int wf, int cs, int H, int W, float scale,
+                                                                   float* flow, float* mask, int first) {
+    const long n = (long)H * W;
+    const float inv_sf = 1.0f / scale;
+    const int hs = 4 * hf, ws = 4 * wf;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W), x = (int)(i - (long)y * W);
+        int y0, y1, x0, x1;
+        float wy, wx;
+        bilin_setup(y, inv_sf, hs, &y0, &y1, &wy);
+        bilin_setup(x, inv_sf, ws, &x0, &x1, &wx);
+        auto at = [&](int Y, int X) {
+            return t96 + ((size_t)(Y >> 2) * wf + (X >> 2)) * cs + ((Y & 1) * 2 + (X & 1)) * 4 + ((Y >> 1) & 1) * 2 + ((X >> 1) & 1);
+        };
+        const float *p00 = at(y0, x0), *p01 = at(y0, x1), *p10 = at(y1, x0), *p11 = at(y1, x1);
+        float v[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+            v[c] = (p00[16 * c] * (1.f - wx) + p01[16 * c] * wx) * (1.f - wy) + (p10[16 * c] * (1.f - wx) + p11[16 * c] * wx) * wy;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) flow[i * 4 + c] = (first ? 0.f : flow[i * 4 + c]) + v[c] * scale;
+        mask[i] = (first ? 0.f : mask[i]) + v[4];
+    }
+}
+
 // merged = warp(I0, flow[:2]) * sigmoid(mask) + warp(I1, flow[2:4]) * (1 - sigmoid(mask)); crop to H x W;
 // optional fp32 RGB; uint8 BGR = round_half_even(clamp(x, 0, 1) * 255)
 __global__ __launch_bounds__(256) void ifnet_blend_kernel(const float* __restrict__ i0, const float* __restrict__ i1,
@@ -277,6 +380,22 @@ void launch_depth_to_space4(const float* src, int h, int w, int cs, float* dst, 
 void launch_ifnet_accumulate(const float* tmp, int hs, int ws, int H, int W, float scale, float* flow, float* mask, int first,
                              hipStream_t st) {
     hipLaunchKernelGGL(ifnet_accumulate_kernel, dim3(ifn_grid((long)H * W)), dim3(256), 0, st, tmp, hs, ws, H, W, scale, flow, mask, first);
+}
+void launch_ifnet_stage_input(DType dt, const float* i0, const float* i1, const float* flow, const float* mask, int H, int W, float timestep,
+                              int s, void* dst, int dst_channels, hipStream_t st) {
+    if (dst_channels > 64 || (dst_channels & 7) || H % (2 * s) || W % (2 * s)) throw Error(1, "ifnet stage input: bad shape");
+    const int hs = H / s, ws = W / s;
+    const long blocks = ((long)(hs / 2) * (ws / 2) + 63) / 64;
+    const dim3 g((unsigned)(blocks < 8192 ? blocks : 8192)), b(256);
+    const float inv_sf = 1.0f / (1.0f / s), fmul = 1.0f / s;
+    if (flow && !mask) throw Error(1, "ifnet stage input: flow without mask");
+#define FW_SI(T, CIN) hipLaunchKernelGGL((ifnet_stage_input_kernel<T, CIN>), g, b, 0, st, i0, i1, flow, mask, H, W, timestep, inv_sf, fmul, hs, ws, (T*)dst, dst_channels)
+    if (dt == DT_BF16) { if (flow) FW_SI(__bf16, 12); else FW_SI(__bf16, 7); }
+    else { if (flow) FW_SI(_Float16, 12); else FW_SI(_Float16, 7); }
+#undef FW_SI
+}
+void launch_ifnet_accumulate_d2s(const float* t96, int hf, int wf, int cs, int H, int W, float scale, float* flow, float* mask, int first, hipStream_t st) {
+    hipLaunchKernelGGL(ifnet_accumulate_d2s_kernel, dim3(ifn_grid((long)H * W)), dim3(256), 0, st, t96, hf, wf, cs, H, W, scale, flow, mask, first);
 }
 void launch_ifnet_blend(const float* i0, const float* i1, const float* flow, const float* mask, int Hp, int Wp, int H, int W,
                         uint8_t* out_bgr, float* out_rgb, hipStream_t st) {
