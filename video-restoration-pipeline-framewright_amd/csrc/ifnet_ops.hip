@@ -137,6 +137,34 @@ __global__ __launch_bounds__(256) void unshuffle_cast_kernel(const S* __restrict
     }
 }
 
+// The same for a typed source with an even channel count (between the two stride-2 convs of an IFBlock): a thread owns 8 output channels
+// = 2 input channels x 4 sub-pixels: four 4-byte loads and one 16-byte store where the kernel above did eight 2-byte loads and stores.
+template <typename T>
+__global__ __launch_bounds__(256) void unshuffle_typed8_kernel(const T* __restrict__ src, int h, int w, int C, int src_cstride, T* dst, int Cpad) {
+    const int wo = w / 2, groups = Cpad / 8;
+    const long n = (long)(h / 2) * wo * groups;
+    typedef T t2 __attribute__((ext_vector_type(2)));
+    typedef T t8 __attribute__((ext_vector_type(8)));
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % groups);
+        const long pix = i / groups;
+        const int y = (int)(pix / wo), x = (int)(pix - (long)y * wo);
+        const int c = 2 * g;                      // output channels 8 g .. 8 g + 7 = input channels c, c + 1, sub-pixels 0 .. 3
+        t8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (T)0.f;
+        if (c < C) {
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {
+                const t2 v = *reinterpret_cast<const t2*>(src + ((size_t)(2 * y + (sub >> 1)) * w + (2 * x + (sub & 1))) * src_cstride + c);
+                o[sub] = v[0];
+                o[4 + sub] = v[1];
+            }
+        }
+        *reinterpret_cast<t8*>(dst + pix * Cpad + 8 * g) = o;
+    }
+}
+
 // lastconv glue: src fp32 [h][w][cs], channel n = ((c6*4 + qy*2 + qx)*4 + py*2 + px)  ->  dst [4h][4w][6]:
 // ConvTranspose2d(k4,s2,p1) computed as a 3x3 conv with 4 parity groups (py,px), followed by PixelShuffle(2) (qy,qx).
 __global__ __launch_bounds__(256) void depth_to_space4_kernel(const float* __restrict__ src, int h, int w, int cs, float* dst) {
@@ -362,6 +390,14 @@ void launch_ifnet_build_x(const float* i0, const float* i1, const float* flow, c
 void launch_unshuffle2_cast(DType dt, const void* src, bool src_f32, int h, int w, int C, int src_cstride, void* dst,
                             int dst_channels, hipStream_t st) {
     dim3 g(ifn_grid((long)(h / 2) * (w / 2) * dst_channels)), b(256);
+    if (!src_f32 && !(C & 1) && !(src_cstride & 1) && !(dst_channels & 7) && !((size_t)src & 3) && !((size_t)dst & 15)) {
+        const dim3 g8(ifn_grid((long)(h / 2) * (w / 2) * (dst_channels / 8)));
+        if (dt == DT_BF16)
+            hipLaunchKernelGGL((unshuffle_typed8_kernel<__bf16>), g8, b, 0, st, (const __bf16*)src, h, w, C, src_cstride, (__bf16*)dst, dst_channels);
+        else
+            hipLaunchKernelGGL((unshuffle_typed8_kernel<_Float16>), g8, b, 0, st, (const _Float16*)src, h, w, C, src_cstride, (_Float16*)dst, dst_channels);
+        return;
+    }
     if (dt == DT_BF16) {
         if (src_f32)
             hipLaunchKernelGGL((unshuffle_cast_kernel<__bf16, float>), g, b, 0, st, (const float*)src, h, w, C, src_cstride, (__bf16*)dst, dst_channels);
