@@ -38,6 +38,12 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
             if (p_in.chan_scale) p.chan_scale = p_in.chan_scale + 32 * CT * g;
             p.out_coff = p_in.out_coff + 32 * CT * g;
             p.f32_coff = p_in.f32_coff + 32 * CT * g;
+            if (p_in.f32_native) {       // accumulator-native fp32 planes: one region per group
+                const size_t gs = (size_t)g * p_in.f32_gstride;
+                if (p_in.res1) p.res1 = p_in.res1 + gs;
+                if (p_in.res2) p.res2 = p_in.res2 + gs;
+                if (p_in.out_f32) p.out_f32 = p_in.out_f32 + gs;
+            }
         }
     }
     using SM = Smem<CT>;
@@ -546,7 +552,7 @@ void launch_conv3x3(DType dt, int cout_tiles, ConvEpilogue epi, const ConvParams
         throw Error(1, "conv3x3: bad output plane stride");
     if (p.out && ((p.out_cstride & 7) || (p.out_coff & 7))) throw Error(1, "conv3x3: output slice must be 16-byte aligned");
     if (p.act == 2 && !p.chan_scale) throw Error(1, "conv3x3: PReLU needs its slopes");
-    if (p.n_groups > 1 && ((epi != EPI_STORE && epi != EPI_RESIDUAL) || p.n_groups > 64 || p.wpk_gstride <= 0 || (p.wpk_gstride & 15) || p.f32_native))
+    if (p.n_groups > 1 && ((epi != EPI_STORE && epi != EPI_RESIDUAL) || p.n_groups > 64 || p.wpk_gstride <= 0 || (p.wpk_gstride & 15) || (p.f32_native && p.f32_gstride < (long)f32_native_elems(p.H, p.W, cout_tiles))))
         throw Error(1, "conv3x3: output-channel groups need EPI_STORE / EPI_RESIDUAL and a 16-byte weight stride");
     if (p.out_lo && (cout_tiles != 2 || !p.out || epi == EPI_IMAGE)) throw Error(1, "conv3x3: out_lo needs a 64-channel typed output");
     if (epi == EPI_RESIDUAL_SPLIT) {

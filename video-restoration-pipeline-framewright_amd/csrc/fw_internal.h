@@ -70,8 +70,10 @@ struct ConvParams {
     // EPI_STORE / EPI_RESIDUAL: n_groups > 1 runs that many convolutions of 32 * cout_tiles output channels each in ONE launch
     // (grid.y = group): group g reads its weights wpk_gstride bytes further on and shifts bias, chan_scale, out_coff and f32_coff
     // by 32 * cout_tiles * g - the output-channel groups of a wide conv on a small feature map side by side (IFNet)
+    // (with f32_native the groups' fp32 planes are f32_gstride floats apart: f32_native_elems(H, W, cout_tiles) or more)
     int n_groups;
     long wpk_gstride;
+    long f32_gstride;
 };
 
 // Number of floats of an accumulator-native fp32 side buffer for an H x W problem with 32*cout_tiles channels:

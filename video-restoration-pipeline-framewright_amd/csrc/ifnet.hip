@@ -170,6 +170,7 @@ struct fw_ifnet {
     int graph_mode = 0;
     bool merge_groups = true;   // the 64-channel output groups of a conv in one launch (FW_IFNET_MERGE_GROUPS=0: A/B)
     bool fuse_glue = true;      // an IFBlock's input in one kernel, depth-to-space inside the accumulate (FW_IFNET_FUSE_GLUE=0: A/B)
+    bool native_trunk = true;   // the ResConv chain's fp32 trunk in the conv kernel's accumulator-native layout (FW_IFNET_NATIVE_TRUNK=0: A/B)
     bool warmed = false;
     struct GraphEntry {
         int H, W;
@@ -239,7 +240,7 @@ Plan make_plan(int H, int W) {
         a0 = std::max(a0, hs / 2 * (ws / 2) * c2p * 2);
         u1 = std::max(u1, hs / 4 * (ws / 4) * 4 * c2p * 2);
         feat = std::max(feat, hs / 4 * (ws / 4) * cp * 2);
-        f32 = std::max(f32, hs / 4 * (ws / 4) * cp * 4);
+        f32 = std::max(f32, std::max(hs / 4 * (ws / 4) * cp * 4, f32_native_elems((int)(hs / 4), (int)(ws / 4), 2) * (cp / 64) * 4));
         t96 = std::max(t96, hs / 4 * (ws / 4) * 96 * 4);
         tmp = std::max(tmp, hs * ws * 6 * 4);
     }
@@ -258,7 +259,7 @@ Plan make_plan(int H, int W) {
 }
 
 void run_conv(const fw_ifnet* n, const Conv& cv, const void* x, int h, int w, void* out, float* out_f32, int act, const float* res,
-              const float* beta, int post_act, hipStream_t st) {
+              const float* beta, int post_act, hipStream_t st, bool trunk = false) {
     const bool merged = n->merge_groups && cv.wall.p;
     for (const auto& g : cv.groups) {
         if (merged && g.off > 0) break;   // group 0's launch carries all of them
@@ -284,6 +285,17 @@ void run_conv(const fw_ifnet* n, const Conv& cv, const void* x, int h, int w, vo
         p.post_act = post_act;
         p.f32_cstride = cv.cout_pad;
         p.f32_coff = g.off;
+        if (trunk && n->native_trunk && cv.cout_pad % 64 == 0) {
+            // the fp32 trunk of the ResConv chain in the accumulator-native layout (one region per 64-channel group): a KiB per
+            // wave-instruction instead of 16 pixels x 64 bytes; only these epilogues ever read it
+            const size_t ge = f32_native_elems(h, w, 2), gi = (size_t)g.off / 64;
+            p.f32_native = 1;
+            p.f32_gstride = (long)ge;
+            if (!merged) {
+                if (p.out_f32) p.out_f32 += gi * ge;
+                if (p.res1) p.res1 += gi * ge;
+            }
+        }
         if (merged) {
             p.wpk = cv.wall.p;
             p.bias = (const float*)cv.ball.p;
@@ -321,9 +333,9 @@ void forward(fw_ifnet* n, const uint8_t* d0, const uint8_t* d1, int H, int W, fl
         const int hf = hs / 4, wf = wsz / 4;
         void *feat = ws + pl.featA, *nxt = ws + pl.featB;
         float *feat32 = (float*)(ws + pl.f32A), *nxt32 = (float*)(ws + pl.f32B);
-        run_conv(n, b.conv01, u1, hf, wf, feat, feat32, 1, nullptr, nullptr, 0, st);
+        run_conv(n, b.conv01, u1, hf, wf, feat, feat32, 1, nullptr, nullptr, 0, st, true);
         for (int j = 0; j < NRES; ++j) {   // ResConv: lrelu(conv(x) * beta + x)
-            run_conv(n, b.res[j], feat, hf, wf, nxt, nxt32, 0, feat32, (const float*)b.beta[j].p, 1, st);
+            run_conv(n, b.res[j], feat, hf, wf, nxt, nxt32, 0, feat32, (const float*)b.beta[j].p, 1, st, true);
             std::swap(feat, nxt);
             std::swap(feat32, nxt32);
         }
@@ -370,6 +382,7 @@ int fw_ifnet_create(int device_id, int dtype, fw_ifnet** out) {
         if (const char* e = getenv("FW_IFNET_GRAPH")) n->graph_mode = atoi(e);
         if (const char* e = getenv("FW_IFNET_MERGE_GROUPS")) n->merge_groups = atoi(e) != 0;
         if (const char* e = getenv("FW_IFNET_FUSE_GLUE")) n->fuse_glue = atoi(e) != 0;
+        if (const char* e = getenv("FW_IFNET_NATIVE_TRUNK")) n->native_trunk = atoi(e) != 0;
         for (int i = 0; i < NBLK; ++i) {
             Block& b = n->blk[i];
             b.c = CH[i];
