@@ -456,6 +456,19 @@ int fw_ifnet_finalize(fw_ifnet* n) {
             }
             std::vector<float> w3, b3;
             convtranspose_as_3x3(b.h_wl.data(), b.h_bl.data(), c, 24, &w3, &b3);
+            if (n->fuse_glue) {
+                // the accumulate kernel reads lastconv's output in place: channel (sub-position of the 4 x 4 block) * 6 + c6 instead of
+                // c6 * 16 + sub-position, so that the 5 values a tap needs are contiguous (as they were in the depth-to-space copy)
+                std::vector<float> wq(w3.size()), bq(b3.size());
+                const size_t row = (size_t)c * 9;
+                for (int nn = 0; nn < 96; ++nn) {
+                    const int c6 = nn / 16, pos = nn % 16, np = pos * 6 + c6;
+                    std::copy(w3.begin() + nn * row, w3.begin() + (nn + 1) * row, wq.begin() + np * row);
+                    bq[np] = b3[nn];
+                }
+                w3.swap(wq);
+                b3.swap(bq);
+            }
             b.last.build(n->dt, w3, b3, 96, c, b.cp, 96);
         }
         n->built = true;
