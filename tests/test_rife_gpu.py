@@ -264,3 +264,23 @@ def test_fused_block_input_and_accumulate_equal_the_separate_kernels(hip_lib, mo
         eng.close()
     assert np.abs(res["1"][0] - res["0"][0]).max() < tol
     assert np.abs(res["1"][1] - res["0"][1]).max() <= 1
+
+
+def test_narrow_output_groups_give_identical_frames(hip_lib, monkeypatch):
+    """The conv chains of blocks with few tiles run 32-channel output groups (twice the workgroups); a group's accumulation order does not
+    depend on its width, so the frames are those of the 64-channel groups (FW_IFNET_NARROW=0), with and without the native fp32 trunk."""
+    sd = synthetic_ifnet_state(seed=5)
+    fr = synthetic_frames(2, 96, 160, seed=12)
+    a, b = torch.from_numpy(fr[0]).cuda(), torch.from_numpy(fr[1]).cuda()
+    outs = []
+    for narrow, native in (("1", "1"), ("0", "1"), ("1", "0")):
+        monkeypatch.setenv("FW_IFNET_NARROW", narrow)
+        monkeypatch.setenv("FW_IFNET_NATIVE_TRUNK", native)
+        eng = RF.IFNetEngine("f16")
+        eng.load_state_dict(sd)
+        rgb = torch.empty((96, 160, 3), dtype=torch.float32, device="cuda")
+        eng.interpolate_device(a, b, 0.5, out_rgb_f32=rgb)
+        torch.cuda.synchronize()
+        outs.append(rgb.cpu())
+        eng.close()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

@@ -525,6 +525,8 @@ static void launch_typed(int cout_tiles, ConvEpilogue epi, const ConvParams& p, 
         hipLaunchKernelGGL((conv3x3_mfma_kernel<T, 2, EPI_STORE>), grid, block, 0, stream, p);
     else if (cout_tiles == 2 && epi == EPI_RESIDUAL)
         hipLaunchKernelGGL((conv3x3_mfma_kernel<T, 2, EPI_RESIDUAL>), grid, block, 0, stream, p);
+    else if (cout_tiles == 1 && epi == EPI_RESIDUAL)   // 32-channel groups of a wide conv on a small map (IFNet's low-resolution blocks)
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<T, 1, EPI_RESIDUAL>), grid, block, 0, stream, p);
     else if (cout_tiles == 2 && epi == EPI_RESIDUAL_SPLIT)
         hipLaunchKernelGGL((conv3x3_mfma_kernel<T, 2, EPI_RESIDUAL_SPLIT>), grid, block, 0, stream, p);
     else if (cout_tiles == 1 && epi == EPI_IMAGE)

@@ -60,6 +60,8 @@ struct Conv {
     std::vector<Group> groups;
     DevBuf wall, ball;       // every group's weights / biases in one buffer each, when all groups are 64 channels wide:
     size_t gstride = 0;      // the groups then run side by side in one launch (ConvParams::n_groups)
+    DevBuf nwall;            // the same conv as 32-channel groups (one launch, ball serves both): twice the workgroups with half the
+    size_t ngstride = 0;     // MFMAs each, for maps of a few tiles (build(..., narrow = true))
     void release() {
         for (auto& g : groups) {
             g.w.release();
@@ -68,10 +70,11 @@ struct Conv {
         groups.clear();
         wall.release();
         ball.release();
-        gstride = 0;
+        nwall.release();
+        gstride = ngstride = 0;
     }
     // w: [cout][cin][3][3] fp32 (already transformed), zero-padded to [cout_pad][cin_pad]
-    void build(DType dt, const std::vector<float>& w, const std::vector<float>& b, int cout, int cin, int cin_p, int cout_p) {
+    void build(DType dt, const std::vector<float>& w, const std::vector<float>& b, int cout, int cin, int cin_p, int cout_p, bool narrow = false) {
         release();
         cin_pad = cin_p;
         cout_pad = cout_p;
@@ -103,6 +106,14 @@ struct Conv {
             upload(wall, all.data(), all.size() * 2);
             upload(ball, bp.data(), bp.size() * 4);
             gstride = n * 2;
+            if (narrow) {
+                const size_t n1 = pack_conv3x3_weights(dt, nullptr, 32, cin_p, 1, chunks, nullptr);
+                std::vector<uint16_t> all1(n1 * (cout_p / 32));
+                for (int g = 0; g < cout_p / 32; ++g)
+                    pack_conv3x3_weights(dt, wp.data() + (size_t)g * 32 * cin_p * 9, 32, cin_p, 1, chunks, all1.data() + g * n1);
+                upload(nwall, all1.data(), all1.size() * 2);
+                ngstride = n1 * 2;
+            }
         }
     }
 };
@@ -171,6 +182,8 @@ struct fw_ifnet {
     bool merge_groups = true;   // the 64-channel output groups of a conv in one launch (FW_IFNET_MERGE_GROUPS=0: A/B)
     bool fuse_glue = true;      // an IFBlock's input in one kernel, depth-to-space inside the accumulate (FW_IFNET_FUSE_GLUE=0: A/B)
     bool native_trunk = true;   // the ResConv chain's fp32 trunk in the conv kernel's accumulator-native layout (FW_IFNET_NATIVE_TRUNK=0: A/B)
+    bool narrow_groups = true;  // 32-channel output groups for the conv chains of blocks with few tiles (FW_IFNET_NARROW=0: A/B;
+    long narrow_below = 128;    //   FW_IFNET_NARROW_BELOW: below that many 64-channel workgroups per launch)
     bool warmed = false;
     struct GraphEntry {
         int H, W;
@@ -259,8 +272,9 @@ Plan make_plan(int H, int W) {
 }
 
 void run_conv(const fw_ifnet* n, const Conv& cv, const void* x, int h, int w, void* out, float* out_f32, int act, const float* res,
-              const float* beta, int post_act, hipStream_t st, bool trunk = false) {
+              const float* beta, int post_act, hipStream_t st, bool trunk = false, bool narrow = false) {
     const bool merged = n->merge_groups && cv.wall.p;
+    narrow = narrow && merged && cv.nwall.p;
     for (const auto& g : cv.groups) {
         if (merged && g.off > 0) break;   // group 0's launch carries all of them
         ConvParams p{};
@@ -288,7 +302,7 @@ void run_conv(const fw_ifnet* n, const Conv& cv, const void* x, int h, int w, vo
         if (trunk && n->native_trunk && cv.cout_pad % 64 == 0) {
             // the fp32 trunk of the ResConv chain in the accumulator-native layout (one region per 64-channel group): a KiB per
             // wave-instruction instead of 16 pixels x 64 bytes; only these epilogues ever read it
-            const size_t ge = f32_native_elems(h, w, 2), gi = (size_t)g.off / 64;
+            const size_t ge = f32_native_elems(h, w, narrow ? 1 : 2), gi = (size_t)g.off / 64;
             p.f32_native = 1;
             p.f32_gstride = (long)ge;
             if (!merged) {
@@ -301,8 +315,13 @@ void run_conv(const fw_ifnet* n, const Conv& cv, const void* x, int h, int w, vo
             p.bias = (const float*)cv.ball.p;
             p.n_groups = (int)cv.groups.size();
             p.wpk_gstride = (long)cv.gstride;
+            if (narrow) {
+                p.wpk = cv.nwall.p;
+                p.n_groups = cv.cout_pad / 32;
+                p.wpk_gstride = (long)cv.ngstride;
+            }
         }
-        launch_conv3x3(n->dt, g.ct, res ? EPI_RESIDUAL : EPI_STORE, p, st);
+        launch_conv3x3(n->dt, narrow ? 1 : g.ct, res ? EPI_RESIDUAL : EPI_STORE, p, st);
     }
 }
 
@@ -333,9 +352,13 @@ void forward(fw_ifnet* n, const uint8_t* d0, const uint8_t* d1, int H, int W, fl
         const int hf = hs / 4, wf = wsz / 4;
         void *feat = ws + pl.featA, *nxt = ws + pl.featB;
         float *feat32 = (float*)(ws + pl.f32A), *nxt32 = (float*)(ws + pl.f32B);
-        run_conv(n, b.conv01, u1, hf, wf, feat, feat32, 1, nullptr, nullptr, 0, st, true);
+        // few tiles (the low-resolution blocks): 32-channel groups - twice the workgroups, half the MFMAs each.  One choice for the whole
+        // chain: the native fp32 trunk's layout follows the group width.
+        const long tiles = (long)(f32_native_elems(hf, wf, 1) / (512 * 32));
+        const bool narrow = n->narrow_groups && tiles * (b.cp / 64) < n->narrow_below;
+        run_conv(n, b.conv01, u1, hf, wf, feat, feat32, 1, nullptr, nullptr, 0, st, true, narrow);
         for (int j = 0; j < NRES; ++j) {   // ResConv: lrelu(conv(x) * beta + x)
-            run_conv(n, b.res[j], feat, hf, wf, nxt, nxt32, 0, feat32, (const float*)b.beta[j].p, 1, st, true);
+            run_conv(n, b.res[j], feat, hf, wf, nxt, nxt32, 0, feat32, (const float*)b.beta[j].p, 1, st, true, narrow);
             std::swap(feat, nxt);
             std::swap(feat32, nxt32);
         }
@@ -383,6 +406,8 @@ int fw_ifnet_create(int device_id, int dtype, fw_ifnet** out) {
         if (const char* e = getenv("FW_IFNET_MERGE_GROUPS")) n->merge_groups = atoi(e) != 0;
         if (const char* e = getenv("FW_IFNET_FUSE_GLUE")) n->fuse_glue = atoi(e) != 0;
         if (const char* e = getenv("FW_IFNET_NATIVE_TRUNK")) n->native_trunk = atoi(e) != 0;
+        if (const char* e = getenv("FW_IFNET_NARROW")) n->narrow_groups = atoi(e) != 0;
+        if (const char* e = getenv("FW_IFNET_NARROW_BELOW")) n->narrow_below = atol(e);
         for (int i = 0; i < NBLK; ++i) {
             Block& b = n->blk[i];
             b.c = CH[i];
@@ -447,9 +472,9 @@ int fw_ifnet_finalize(fw_ifnet* n) {
             for (int co = 0; co < c; ++co)
                 for (int ci = 0; ci < c / 2; ++ci)
                     for (int t = 0; t < 9; ++t) w1[((size_t)co * b.c2p + ci) * 9 + t] = b.h_w01[((size_t)co * (c / 2) + ci) * 9 + t];
-            b.conv01.build(n->dt, stride2_as_unshuffled(w1.data(), c, b.c2p), b.h_b01, c, 4 * b.c2p, 4 * b.c2p, b.cp);
+            b.conv01.build(n->dt, stride2_as_unshuffled(w1.data(), c, b.c2p), b.h_b01, c, 4 * b.c2p, 4 * b.c2p, b.cp, true);
             for (int j = 0; j < NRES; ++j) {
-                b.res[j].build(n->dt, b.h_wr[j], b.h_br[j], c, c, b.cp, b.cp);
+                b.res[j].build(n->dt, b.h_wr[j], b.h_br[j], c, c, b.cp, b.cp, true);
                 std::vector<float> beta(b.cp, 0.f);
                 for (int k = 0; k < c; ++k) beta[k] = b.h_beta[j][k];
                 upload(b.beta[j], beta.data(), beta.size() * 4);
