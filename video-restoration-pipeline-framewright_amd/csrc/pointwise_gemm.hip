@@ -30,8 +30,13 @@ constexpr int G_W_PIECES = 2 * (G_N / 16) * 64; // 2048 pieces: 2 chunks x 16 ch
 constexpr int G_STAGE = G_A_PIECES + G_W_PIECES;
 static_assert(2 * G_STAGE * 16 <= 160 * 1024, "LDS");
 
-template <typename T, int MODE>
+// NH = 2: a workgroup tile is 256 pixels x 128 output channels (one half of a packed 256-channel tile; a wave owns 4 channel tiles
+// instead of 8) - for launches whose 256 x 256 tiles would leave half of the CUs idle (NAFNet's middle level: 8160 pixels x 1024
+// channels = 128 tiles).  Not for PW_GATE (its x1 / x2 pairing lives inside a wave's 8 tiles).
+template <typename T, int MODE, int NH = 1>
 __global__ __launch_bounds__(512, 2) void pw_gemm_kernel(const PointwiseParams p) {
+    constexpr int NJ = 8 / NH;                  // 16-channel tiles per wave
+    static_assert(NH == 1 || MODE != PW_GATE, "half tiles: not for the gate");
     __shared__ __attribute__((aligned(16))) uint4 lds[2 * G_STAGE];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -42,7 +47,7 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_kernel(const PointwiseParams p
     const int xcd = blockIdx.x & 7;
     const int qn = NB >> 3, rn = NB & 7;
     const int lb = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blockIdx.x >> 3);
-    const int n_tiles = p.N_tiles / 8;                       // 256-channel tiles (N_tiles counts 32-channel tiles)
+    const int n_tiles = p.N_tiles / 8 * NH;                  // 256- (NH = 2: 128-) channel tiles (N_tiles counts 32-channel tiles)
     const long m_tiles = (p.M + G_PX - 1) / G_PX;
     const long ntiles = m_tiles * n_tiles;                   // t = mt * n_tiles + nt: a workgroup's consecutive tiles share A rows
     const long t_lo = lb * ntiles / NB, t_hi = (long)(lb + 1) * ntiles / NB;
@@ -79,8 +84,17 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_kernel(const PointwiseParams p
         const char* a_src = a_b + mt * G_PX * row_bytes + ((long)f_kb * G_KB + 32 * ch) * 2;
         const unsigned a_dst = (unsigned)(stage * G_STAGE + ch * (G_PX * 4) + (4 * pg + 3) * 64);
         glds16_batch_a4(a_src, voff, lds_base + a_dst * 16u);
-        const char* w_src = w_b + ((size_t)nt * nkb + f_kb) * (G_W_PIECES * 16) + (4 * wave + 4) * 1024;
-        glds16_batch_w<4>(w_src, lane16, lds_base + (unsigned)(stage * G_STAGE + G_A_PIECES + (4 * wave + 4) * 64) * 16u);
+        if constexpr (NH == 1) {
+            const char* w_src = w_b + ((size_t)nt * nkb + f_kb) * (G_W_PIECES * 16) + (4 * wave + 4) * 1024;
+            glds16_batch_w<4>(w_src, lane16, lds_base + (unsigned)(stage * G_STAGE + G_A_PIECES + (4 * wave + 4) * 64) * 16u);
+        } else {
+            // half tile: per chunk the 8 KiB of channel tiles 8 half .. 8 half + 7; wave w: chunk w >> 2, tiles 2 (w & 3), + 1 -> LDS [chunk][8 tiles]
+            const int wc = wave >> 2, wt = 2 * (wave & 3);
+            const char* w_src = w_b + (((size_t)(nt >> 1) * nkb + f_kb) * 2 + wc) * (16 * 1024) + ((nt & 1) * 8 + wt) * 1024;
+            const unsigned w_dst = lds_base + (unsigned)(stage * G_STAGE + G_A_PIECES + (wc * 8 + wt) * 64) * 16u;
+            glds16(w_src, lane16, w_dst);
+            glds16(w_src + 1024, lane16, w_dst + 1024u);
+        }
         if (++f_kb == nkb) {
             f_kb = 0;
             ++f_t;
@@ -95,7 +109,7 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_kernel(const PointwiseParams p
         rd_b[t] = px * 4 + (sl ^ halo_swz(px));
     }
 
-    f32x4 acc[4][8];
+    f32x4 acc[4][NJ];
     issue(0);
     long n = 0;
     for (long t = t_lo; t < t_hi; ++t) {
@@ -104,7 +118,7 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_kernel(const PointwiseParams p
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         for (int kb = 0; kb < nkb; ++kb, ++n) {
             // item n has landed (each wave waits for its own DMAs, then the barrier); a tile's first item after an epilogue was
@@ -116,7 +130,7 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_kernel(const PointwiseParams p
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const uint4* ai = st + c * (G_PX * 4);
-                const uint4* wi = st + G_A_PIECES + (c * 16 + 8 * ch) * 64 + lane;
+                const uint4* wi = st + G_A_PIECES + (c * (16 / NH) + NJ * ch) * 64 + lane;
                 uint4 xb[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) xb[i] = ai[rd_b[i]];
@@ -125,8 +139,8 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_kernel(const PointwiseParams p
                 wf[1] = wi[64];
                 FW_SB();
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (j + 2 < 8) wf[(j + 2) % 3] = wi[(j + 2) * 64];
+                for (int j = 0; j < NJ; ++j) {
+                    if (j + 2 < NJ) wf[(j + 2) % 3] = wi[(j + 2) * 64];
                     FW_SB();
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[i][j] = Op<T>::mfma16(wf[j % 3], xb[i], acc[i][j]);
@@ -142,8 +156,8 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_kernel(const PointwiseParams p
         if constexpr (MODE == PW_RESIDUAL) {
             // y = res + (acc + bias) * chan_scale into the fp32 stream
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int nn = 256 * nt + 16 * (8 * ch + j) + 4 * sl;
+            for (int j = 0; j < NJ; ++j) {
+                const int nn = (256 / NH) * nt + 16 * (NJ * ch + j) + 4 * sl;
                 const f32x4 bs = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nn) : f32x4{0.f, 0.f, 0.f, 0.f};
                 const f32x4 cs = *reinterpret_cast<const f32x4*>(p.chan_scale + nn);
 #pragma unroll
@@ -159,10 +173,10 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_kernel(const PointwiseParams p
             // typed output, 16 bytes per lane: v_permlane16_swap pairs the fragments of two neighbouring 16-channel tiles so that
             // a lane owns one whole 8-channel slot of its pixel (conv3x3_mfma.hip's store).  PW_GATE: the wave's tiles 0-3 are
             // x1, tiles 4-7 the matching x2 channels (pack_pointwise_weights16 lays the rows out that way): out = x1 * x2.
-            constexpr int NOUT = MODE == PW_GATE ? 4 : 8;        // output tiles of 16 channels per wave
+            constexpr int NOUT = MODE == PW_GATE ? 4 : NJ;       // output tiles of 16 channels per wave
             const int ls = (sl & 1) ? 2 + (sl >> 1) : (sl >> 1);
             const long n_half = (long)p.N_tiles * 16;            // PW_GATE: bias of x2 sits N / 2 behind x1's
-            const int n_wave = MODE == PW_GATE ? 128 * nt + 64 * ch : 256 * nt + 128 * ch;   // first output channel of this wave
+            const int n_wave = MODE == PW_GATE ? 128 * nt + 64 * ch : (256 / NH) * nt + (128 / NH) * ch;   // first output channel of this wave
 #pragma unroll
             for (int jp = 0; jp < NOUT / 2; ++jp) {
                 f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, b2 = b0, b3 = b0;
@@ -248,7 +262,13 @@ bool pointwise_gemm_eligible(const PointwiseParams& p) {
 
 void launch_pointwise_gemm(DType dt, const PointwiseParams& p, hipStream_t st) {
     if (!pointwise_gemm_eligible(p)) throw Error(1, "pointwise gemm: shape not eligible");
-    const long tiles = ((p.M + G_PX - 1) / G_PX) * (p.N_tiles / 8);
+    long tiles = ((p.M + G_PX - 1) / G_PX) * (p.N_tiles / 8);
+    static const bool half_on = [] {   // FW_PW_GEMM_HALF=0: always 256-channel tiles (A/B)
+        const char* e = getenv("FW_PW_GEMM_HALF");
+        return !e || atoi(e) != 0;
+    }();
+    const bool half = half_on && p.mode != PW_GATE && 2 * tiles <= gemm_cus();   // 256 x 256 tiles would leave half of the CUs idle
+    if (half) tiles *= 2;
     dim3 grid((unsigned)(tiles < gemm_cus() ? tiles : gemm_cus())), block(512);
 #define FW_G(MODE)                                                                              \
     do {                                                                                        \
@@ -257,10 +277,20 @@ void launch_pointwise_gemm(DType dt, const PointwiseParams& p, hipStream_t st) {
         else                                                                                    \
             hipLaunchKernelGGL((pw_gemm_kernel<_Float16, MODE>), grid, block, 0, st, p);        \
     } while (0)
-    if (p.mode == PW_STORE) FW_G(PW_STORE);
+#define FW_GH(MODE)                                                                             \
+    do {                                                                                        \
+        if (dt == DT_BF16)                                                                      \
+            hipLaunchKernelGGL((pw_gemm_kernel<__bf16, MODE, 2>), grid, block, 0, st, p);       \
+        else                                                                                    \
+            hipLaunchKernelGGL((pw_gemm_kernel<_Float16, MODE, 2>), grid, block, 0, st, p);     \
+    } while (0)
+    if (half && p.mode == PW_STORE) FW_GH(PW_STORE);
+    else if (half) FW_GH(PW_RESIDUAL);
+    else if (p.mode == PW_STORE) FW_G(PW_STORE);
     else if (p.mode == PW_GATE) FW_G(PW_GATE);
     else FW_G(PW_RESIDUAL);
 #undef FW_G
+#undef FW_GH
     FW_HIP_CHECK(hipGetLastError());
 }
 
