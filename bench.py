@@ -89,8 +89,8 @@ def psnr_u8(a, b):
 
 
 def lib_digest():
-    from framewright_amd import _lib
-    return hashlib.sha256(_lib.LIB_PATH.read_bytes()).hexdigest()[:16]
+    from framewright_amd import build as B
+    return B.source_digest()
 
 
 def nafnet_design_bytes(H, W, width=64, enc=(2, 2, 4, 8), mid=12, dec=(2, 2, 2, 2)):

@@ -36,10 +36,11 @@ fetch = tot["FETCH_SIZE"] * 1024 * 2 / n
 write = tot["WRITE_SIZE"] * 1024 / n
 avg_ms = sum(dur_ns.values()) / n / 1e6
 root = Path(__file__).resolve().parent.parent
-lib = root / "video-restoration-pipeline-framewright_amd" / "lib" / "libframewright_hip.so"
+sys.path.insert(0, str(root))
+from framewright_amd import build as _build   # the digest names the build by its sources and flags
 json.dump({
     "kernel": "conv3x3_mfma_kernel + conv3x3_pair_slide_kernel (all instantiations)",
-    "lib_digest": hashlib.sha256(lib.read_bytes()).hexdigest()[:16],
+    "lib_digest": _build.source_digest(),
     "dtype": dtype,
     "launches": n,
     "frames": frames,

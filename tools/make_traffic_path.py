@@ -26,9 +26,10 @@ for f in glob.glob(f"{src}/p*/**/*_counter_collection.csv", recursive=True):
 fetch = tot["FETCH_SIZE"] * 1024 * 2 / forwards
 write = tot["WRITE_SIZE"] * 1024 / forwards
 root = Path(__file__).resolve().parent.parent
-lib = root / "video-restoration-pipeline-framewright_amd" / "lib" / "libframewright_hip.so"
+sys.path.insert(0, str(root))
+from framewright_amd import build as _build   # the digest names the build by its sources and flags
 json.dump({
-    "lib_digest": hashlib.sha256(lib.read_bytes()).hexdigest()[:16],
+    "lib_digest": _build.source_digest(),
     "dtype": dtype,
     "forwards": forwards,
     "hbm_bytes_per_forward": fetch + write,

@@ -54,6 +54,16 @@ def needs_build() -> bool:
     return not (LIB_PATH.exists() and stamp.exists() and stamp.read_text() == _digest(deps))
 
 
+def source_digest() -> str:
+    """16 hex digits that name a BUILD by what went into it (file names and bytes of csrc/*.hip, csrc/*.h, include/*.h, the compile
+    flags) - what lib/.digest holds since the library was linked.  The measured-traffic files under profiles/ carry it, and bench.py
+    quotes their numbers only for the build they were measured on.  (The bytes of the .so itself differ with the directory the tree
+    is built in - __FILE__ strings - so they cannot name a build across checkouts.)"""
+    f = LIB_DIR / ".digest"
+    full = f.read_text().strip() if f.exists() else _digest(sources() + sorted(CSRC.glob("*.h")) + sorted(INCLUDE.glob("*.h")))
+    return full[:16]
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile every .hip under csrc/ for gfx950 and link lib/libframewright_hip.so."""
     deps = sources() + sorted(CSRC.glob("*.h")) + sorted(INCLUDE.glob("*.h"))
