@@ -10,7 +10,10 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 
-template <int SHAPE>
+// ORDER (16x16x32 only): which operand stays while the other cycles through its four registers - 0: B stays for four MFMAs (A changes with
+// every MFMA), 1: A stays, 2: both change with every MFMA, 3: one A and one B register for all of them.  (Does the order in which a
+// kernel walks its fragments change what the chip can sustain at the power cap?)
+template <int SHAPE, int ORDER = 0>
 __global__ __launch_bounds__(512, 2) void mfma_peak_kernel(const uint4* __restrict__ seed, int iters, float* sink,
                                                            unsigned long long* clocks) {
     const int lane = threadIdx.x & 63;
@@ -29,7 +32,8 @@ __global__ __launch_bounds__(512, 2) void mfma_peak_kernel(const uint4* __restri
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i & 3], b[i >> 2], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ORDER == 0 ? (i & 3) : ORDER == 1 ? (i >> 2) : ORDER == 2 ? (i & 3) : 0],
+                                                                 b[ORDER == 0 ? (i >> 2) : ORDER == 1 ? (i & 3) : ORDER == 2 ? ((i + (i >> 2)) & 3) : 0], acc[i], 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) out += acc[i][0];
@@ -59,8 +63,8 @@ __global__ __launch_bounds__(512, 2) void mfma_peak_kernel(const uint4* __restri
 
 // Runs `iters` x 16 (shape 16) or x 8 (shape 32) MFMAs per wave on `blocks` workgroups of 8 waves; returns milliseconds of the
 // launch (HIP events), the summed s_memtime / s_memrealtime deltas of wave 0 of every workgroup in clocks[0..1].
-extern "C" int fw_debug_mfma_peak(int shape, int blocks, int iters, float* ms_out, unsigned long long* clocks_out) {
-    if ((shape != 16 && shape != 32) || blocks < 1 || iters < 1 || !ms_out || !clocks_out) return FW_ERR_INVALID;
+extern "C" int fw_debug_mfma_peak(int shape, int order, int zeros, int blocks, int iters, float* ms_out, unsigned long long* clocks_out) {
+    if ((shape != 16 && shape != 32) || order < 0 || order > 3 || blocks < 1 || iters < 1 || !ms_out || !clocks_out) return FW_ERR_INVALID;
     uint4* seed = nullptr;
     float* sink = nullptr;
     unsigned long long* clk = nullptr;
@@ -73,6 +77,7 @@ extern "C" int fw_debug_mfma_peak(int shape, int blocks, int iters, float* ms_ou
         s = s * 1664525u + 1013904223u;
         h[i] = (uint16_t)(((s >> 16) & 0x8000u) | ((125u + ((s >> 8) & 3u)) << 7) | ((s >> 20) & 0x7fu));
     }
+    if (zeros) memset(h, 0, sizeof(h));   // all-zero operands: nothing toggles in the multipliers
     (void)hipMemcpy(seed, h, sizeof(h), hipMemcpyHostToDevice);
     (void)hipMemset(clk, 0, 16);
     hipEvent_t e0, e1;
@@ -83,7 +88,13 @@ extern "C" int fw_debug_mfma_peak(int shape, int blocks, int iters, float* ms_ou
             (void)hipMemset(clk, 0, 16);
             (void)hipEventRecord(e0, nullptr);
         }
-        if (shape == 16)
+        if (shape == 16 && order == 1)
+            hipLaunchKernelGGL((mfma_peak_kernel<16, 1>), dim3(blocks), dim3(512), 0, nullptr, seed, iters, sink, clk);
+        else if (shape == 16 && order == 2)
+            hipLaunchKernelGGL((mfma_peak_kernel<16, 2>), dim3(blocks), dim3(512), 0, nullptr, seed, iters, sink, clk);
+        else if (shape == 16 && order == 3)
+            hipLaunchKernelGGL((mfma_peak_kernel<16, 3>), dim3(blocks), dim3(512), 0, nullptr, seed, iters, sink, clk);
+        else if (shape == 16)
             hipLaunchKernelGGL(mfma_peak_kernel<16>, dim3(blocks), dim3(512), 0, nullptr, seed, iters, sink, clk);
         else
             hipLaunchKernelGGL(mfma_peak_kernel<32>, dim3(blocks), dim3(512), 0, nullptr, seed, iters, sink, clk);
