@@ -148,7 +148,7 @@ struct PointwiseParams {
     float ln_eps;
     const void* wpk;       // pack_pointwise_weights
     const void* wpk16;     // optional: the same weights in pack_pointwise_weights16's layout - with it, typed inputs and
-                           // K >= 256, cout % 256 == 0, the pipelined GEMM kernel (pointwise_gemm.hip) runs instead
+                           // K >= 128, cout % 256 == 0, the pipelined GEMM kernel (pointwise_gemm.hip) runs instead
     const float* bias;     // [32*N_tiles] or null
     int N_tiles;           // cout / 32
     int mode;

@@ -255,7 +255,7 @@ static int gemm_cus() {
 }
 
 bool pointwise_gemm_eligible(const PointwiseParams& p) {
-    return p.wpk16 && !p.a_f32 && !p.gather2x2 && !p.ln_w && !p.a_scale && p.K >= 256 && (p.K % G_KB) == 0 && (p.N_tiles % 8) == 0 &&
+    return p.wpk16 && !p.a_f32 && !p.gather2x2 && !p.ln_w && !p.a_scale && p.K >= 128 && (p.K % G_KB) == 0 && (p.N_tiles % 8) == 0 &&
            (p.lda % 8) == 0 && (p.mode == PW_STORE || p.mode == PW_GATE || p.mode == PW_RESIDUAL) &&
            (p.mode == PW_RESIDUAL ? p.out_f32 && p.res_f32 && p.chan_scale && (p.ldf % 4) == 0 : p.out_typed && !p.out_f32 && (p.ldo % 8) == 0);
 }

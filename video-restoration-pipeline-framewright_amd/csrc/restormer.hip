@@ -102,9 +102,11 @@ struct RBlock {
     DevBuf n1w, n1b, n2w, n2b, temp, qkv, qkv_dw, proj, pin, ffn_dw, pout;
     DevBuf proj_f32;               // project_out fp32 [c][c]: folded into the attention matrix per forward (fw_attn_proj_pack)
     DevBuf front_qkv, front_ffn;   // pw_dw_fused.hip parameter blocks (c = 48 / 96): norm1 + qkv + qkv_dwconv, norm2 + project_in + dwconv
+    DevBuf qkv16, pin16;           // qkv / project_in in pack_pointwise_weights16's layout, rows padded to 256 (the staged levels: pointwise_gemm.hip)
+    int qkv16_n = 0, pin16_n = 0;  // padded output channels
     int qkv_t = 0, proj_t = 0, pin_t = 0, pout_t = 0;
     void release() {
-        for (DevBuf* b : {&n1w, &n1b, &n2w, &n2b, &temp, &qkv, &qkv_dw, &proj, &pin, &ffn_dw, &pout, &front_qkv, &front_ffn, &proj_f32}) b->release();
+        for (DevBuf* b : {&n1w, &n1b, &n2w, &n2b, &temp, &qkv, &qkv_dw, &proj, &pin, &ffn_dw, &pout, &front_qkv, &front_ffn, &proj_f32, &qkv16, &pin16}) b->release();
     }
 };
 
@@ -143,6 +145,7 @@ struct fw_restormer {
     int red3_t = 0, red2_t = 0;
     bool built = false;
     bool merge_groups = true; // the 64-channel output groups of a 3x3 conv in one launch (FW_REST_MERGE_GROUPS=0: A/B)
+    bool gemm16 = true;       // qkv / project_in of the 192- / 384-channel levels on the pipelined GEMM kernel (FW_REST_GEMM16=0: A/B)
     bool qk_direct = true;    // the fused qkv front writes q / k in the Gram kernel's operand layout (FW_REST_QK_DIRECT=0: pixel-major + transpose pass)
     bool merge_proj = true;   // project_out folded into the attention matrix: one GEMM pass instead of two (FW_REST_MERGE_PROJ=0: A/B)
     bool fuse_front = true;   // LayerNorm + 1x1 + depthwise 3x3 (+ GDFN gate) of the 48- / 96-channel blocks as one kernel (FW_REST_FUSE_FRONT=0: A/B)
@@ -262,9 +265,17 @@ void forward(fw_restormer* n, Arena& A, const uint8_t* d_in, int H, int W, uint8
             }
         } else {
             RUN(fw_layernorm_nhwc(dt, x, cp, M, c, (const float*)b.n1w.p, (const float*)b.n1b.p, 1e-5f, t, cp, cp, st));
-            void* qkv = typ((size_t)M * 3 * cp);
-            RUN(fw_pointwise_nhwc(dt, t, 0, cp, M, cp, b.qkv.p, nullptr, b.qkv_t, qkv, 3 * cp, nullptr, 0, nullptr, nullptr, st));
-            RUN(fw_dwconv3x3_nhwc(dt, qkv, 3 * cp, h, w, 3 * cp, (const float*)b.qkv_dw.p, 0, qkv2, 3 * cp, st));
+            // a typed-store 1x1 GEMM of the staged levels on the pipelined kernel (256-channel tiles: the output rows are qld wide)
+            auto gemm = [&](const DevBuf& w, const DevBuf& w16, int tiles, int n16, void* out, long ld) {
+                PointwiseParams p{};
+                p.a = t; p.lda = cp; p.M = M; p.K = cp; p.wpk = w.p; p.wpk16 = w16.p; p.N_tiles = w16.p ? n16 / 32 : tiles; p.mode = PW_STORE;
+                p.out_typed = out; p.ldo = ld;
+                if (run) launch_pointwise(n->dt, p, st_);
+            };
+            const long qld = b.qkv16.p ? b.qkv16_n : 3 * cp;
+            void* qkv = typ((size_t)M * qld);
+            gemm(b.qkv, b.qkv16, b.qkv_t, b.qkv16_n, qkv, qld);
+            RUN(fw_dwconv3x3_nhwc(dt, qkv, qld, h, w, 3 * cp, (const float*)b.qkv_dw.p, 0, qkv2, 3 * cp, st));
             void* scratch = typ(fw_attn_qk_scratch_elems(M, heads, ch));
             RUN(fw_attn_matrix_mfma(dt, qkv2, 3 * cp, M, cp, heads, ch, (const float*)b.temp.p, aws, scratch, attn, st));
         }
@@ -284,9 +295,15 @@ void forward(fw_restormer* n, Arena& A, const uint8_t* d_in, int H, int W, uint8
             front(b.front_ffn, 2 * hp, PWDW_GATE_GELU, g2, hp);
         } else {
             RUN(fw_layernorm_nhwc(dt, x, cp, M, c, (const float*)b.n2w.p, (const float*)b.n2b.p, 1e-5f, t, cp, cp, st));
-            void* g = typ((size_t)M * 2 * hp);
-            RUN(fw_pointwise_nhwc(dt, t, 0, cp, M, cp, b.pin.p, nullptr, b.pin_t, g, 2 * hp, nullptr, 0, nullptr, nullptr, st));
-            RUN(fw_dwconv3x3_nhwc(dt, g, 2 * hp, h, w, 2 * hp, (const float*)b.ffn_dw.p, 1, g2, hp, st));
+            const long gld = b.pin16.p ? b.pin16_n : 2 * hp;
+            void* g = typ((size_t)M * gld);
+            {
+                PointwiseParams p{};
+                p.a = t; p.lda = cp; p.M = M; p.K = cp; p.wpk = b.pin.p; p.wpk16 = b.pin16.p; p.N_tiles = b.pin16.p ? b.pin16_n / 32 : b.pin_t; p.mode = PW_STORE;
+                p.out_typed = g; p.ldo = gld;
+                if (run) launch_pointwise(n->dt, p, st_);
+            }
+            RUN(fw_dwconv3x3_nhwc(dt, g, gld, h, w, 2 * hp, (const float*)b.ffn_dw.p, 1, g2, hp, st));
         }
         RUN(fw_pointwise_nhwc(dt, g2, 0, hp, M, hp, b.pout.p, nullptr, b.pout_t, nullptr, 0, x, cp, x, (const float*)n->ones.p, st));
         A.top = mark;
@@ -385,6 +402,7 @@ int fw_restormer_create(int device_id, int dim, const int* num_blocks, int num_r
         if (const char* e = getenv("FW_REST_MERGE_PROJ")) n->merge_proj = atoi(e) != 0;
         if (const char* e = getenv("FW_REST_QK_DIRECT")) n->qk_direct = atoi(e) != 0;
         if (const char* e = getenv("FW_REST_MERGE_GROUPS")) n->merge_groups = atoi(e) != 0;
+        if (const char* e = getenv("FW_REST_GEMM16")) n->gemm16 = atoi(e) != 0;
         for (int i = 0; i < 4; ++i) {
             if (num_blocks[i] < 0 || num_blocks[i] > 64 || heads[i] < 1) throw Error(FW_ERR_INVALID, "fw_restormer_create: bad block / head counts");
             n->nblk[i] = num_blocks[i];
@@ -495,6 +513,17 @@ int fw_restormer_finalize(fw_restormer* n) {
                     wdw_f.resize((size_t)nq * 9, 0.f);
                     upload_front(b.front_qkv, wq_f, "norm1.body.weight", "norm1.body.bias", wdw_f, nq, 0);
                 }
+                auto upload16 = [&](DevBuf& dst, const std::vector<float>& w, int rows, int* n_out) {   // [rows][c] -> [pad256(rows)][cp], 16-layout
+                    const int np = pad_to(rows, 256);
+                    std::vector<float> wp((size_t)np * cp, 0.f);
+                    for (int r = 0; r < rows; ++r) std::copy(w.begin() + (size_t)r * c, w.begin() + (size_t)(r + 1) * c, wp.begin() + (size_t)r * cp);
+                    std::vector<uint16_t> pk(pack_pointwise_weights16(dt, nullptr, np, cp, 0, nullptr));
+                    pack_pointwise_weights16(dt, wp.data(), np, cp, 0, pk.data());
+                    upload(dst, pk.data(), pk.size() * 2);
+                    *n_out = np;
+                };
+                const bool gemm16 = n->gemm16 && !fused && cp % 64 == 0 && cp >= 128;
+                if (gemm16) upload16(b.qkv16, wqkv, 3 * cp, &b.qkv16_n);
                 b.proj_t = upload_pointwise(dt, b.proj, H("attn.project_out.weight").data(), c, c, cp);
                 upload(b.proj_f32, H("attn.project_out.weight").data(), (size_t)c * c * 4);
                 // GDFN: x1 rows @ 0, x2 rows @ hp
@@ -507,6 +536,7 @@ int fw_restormer_finalize(fw_restormer* n) {
                         std::copy(di.begin() + (size_t)(half * hid + r) * 9, di.begin() + (size_t)(half * hid + r + 1) * 9, di2.begin() + (size_t)(half * hp + r) * 9);
                     }
                 b.pin_t = upload_pointwise(dt, b.pin, wi2.data(), 2 * hp, c, cp);
+                if (gemm16) upload16(b.pin16, wi2, 2 * hp, &b.pin16_n);
                 upload(b.ffn_dw, di2.data(), di2.size() * 4);
                 if (fused && hp % 32 == 0 && (2 * hp) % 64 == 0) upload_front(b.front_ffn, wi2, "norm2.body.weight", "norm2.body.bias", di2, 2 * hp, 1);
                 b.pout_t = upload_pointwise(dt, b.pout, H("ffn.project_out.weight").data(), c, hid, hp);
