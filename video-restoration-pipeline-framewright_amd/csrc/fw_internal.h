@@ -330,5 +330,23 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     const f32x2 s = x * 0.5f + h;
     return s - h * r;
 }
+// the same, one value, scalar instructions (where register pairs for the packed form are not to be had)
+__device__ __forceinline__ float gelu_erf1(float x) {
+    const float ax = __builtin_fabsf(x);
+    const float z = ax * 0.70710678118654752f;
+    float q = __builtin_fmaf(z, 0.0000430638f, 0.0002765672f);
+    q = __builtin_fmaf(q, z, 0.0001520143f);
+    q = __builtin_fmaf(q, z, 0.0092705272f);
+    q = __builtin_fmaf(q, z, 0.0422820123f);
+    q = __builtin_fmaf(q, z, 0.0705230784f);
+    q = __builtin_fmaf(q, z, 1.0f);
+    q = q * q;
+    q = q * q;
+    q = q * q;
+    q = q * q;
+    const float r = __builtin_amdgcn_rcpf(q);
+    const float hh = ax * 0.5f;
+    return __builtin_fmaf(-hh, r, __builtin_fmaf(x, 0.5f, hh));
+}
 
 }  // namespace fw

@@ -212,9 +212,18 @@ __global__ __launch_bounds__(256, 2) void dwconv3x3_nhwc_kernel(const T* __restr
                 for (int o = 0; o < DW_ROWS; ++o)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
+#ifndef FW_DW_GELU_ERFF
+                        // erf after A&S 7.1.28 (fw_internal.h), scalar: a third fewer VALU instructions than with erff and no spills; the
+                        // packed two-value form needs aligned register pairs and spilled 33 registers here (28.3 against 23.1 us)
                         if (MODE == 1 && half == 0)
-                            res[o][j] = 0.5f * acc[o][j] * (1.0f + erff(acc[o][j] * 0.70710678118654752f));   // (gelu_erf2 measured slower here: 28.3 vs 23.1 us)
-                        else if (MODE == 1)
+                            res[o][j] = gelu_erf1(acc[o][j]);
+                        else
+#else
+                        if (MODE == 1 && half == 0)
+                            res[o][j] = 0.5f * acc[o][j] * (1.0f + erff(acc[o][j] * 0.70710678118654752f));
+                        else
+#endif
+                        if (MODE == 1)
                             res[o][j] *= acc[o][j];
                         else
                             res[o][j] = acc[o][j];
@@ -306,9 +315,18 @@ __global__ __launch_bounds__(256, 2) void dwconv3x3_nhwc_wide_kernel(const T* __
                 for (int o = 0; o < DW_ROWS; ++o)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
+#ifndef FW_DW_GELU_ERFF
+                        // erf after A&S 7.1.28 (fw_internal.h), scalar: a third fewer VALU instructions than with erff and no spills; the
+                        // packed two-value form needs aligned register pairs and spilled 33 registers here (28.3 against 23.1 us)
                         if (MODE == 1 && half == 0)
-                            res[o][j] = 0.5f * acc[o][j] * (1.0f + erff(acc[o][j] * 0.70710678118654752f));   // (gelu_erf2 measured slower here: 28.3 vs 23.1 us)
-                        else if (MODE == 1)
+                            res[o][j] = gelu_erf1(acc[o][j]);
+                        else
+#else
+                        if (MODE == 1 && half == 0)
+                            res[o][j] = 0.5f * acc[o][j] * (1.0f + erff(acc[o][j] * 0.70710678118654752f));
+                        else
+#endif
+                        if (MODE == 1)
                             res[o][j] *= acc[o][j];
                         else
                             res[o][j] = acc[o][j];
