@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the judged profile artefacts of round 2 on the GPU box (run from the repo root through gpurun; ~6 min):
 #   gpurun_out/r02/pmc/p1,p2   FETCH_SIZE / WRITE_SIZE passes of the headline bench (separate passes), p3: MFMA-busy / LDS counters
-#   profiles/r02_traffic.json  per-launch and per-frame HBM traffic from p1 + p2, tagged with the library digest (written first,
+#   profiles/r02_traffic.json  per-launch and per-frame HBM traffic from p1 + p2, tagged with the build's digest (framewright_amd.build.source_digest(): sources + flags; written first,
 #                              so that the bench line that follows quotes the traffic of THIS build)
 #   gpurun_out/r02/bench_{sr,rife,tap,chain}.json   the four bench lines
 #   gpurun_out/r02/stats_{sr,tap,rife,restormer}/   rocprofv3 --kernel-trace --stats summaries
