@@ -1,0 +1,125 @@
+// Diagnostic only (tools/dw_mfma.py): the depthwise 3x3 convolution of the fused LayerNorm -> 1x1 -> depthwise kernels (pw_dw_fused.hip)
+// on the MATRIX CORES.  In pw_dw_fused.hip the depthwise phase is VALU-issue-bound (~1000 issue slots per 64-channel chunk and wave:
+// a conversion per loaded value, half a packed FMA per MAC) and takes 55 % of the kernel.  Here, per channel c and tap row dy,
+//     D[m][n] += sum_k A_dy[m][k] * B[k][n],   m = output column (16), k = input column (32), n = image row (16)
+//     A_dy[m][k] = w[c][dy][k - m] for 0 <= k - m <= 2, else 0   (a Toeplitz band: built in registers with 4 v_perm_b32 from the
+//                  taps, the byte selectors are per-lane constants)
+//     B[k][n]    = y[c][n + dy][col0 + k]                        (one ds_read_b128 per lane from a channel-major LDS tile)
+// i.e. 3 v_mfma_f32_16x16x32_f16 per channel and 16 x 16 outputs: 9 % of their MACs are useful, and it is still several times the
+// VALU rate.  Tile: 64 channels x 16 output rows x 32 output columns from an [64][18][56] f16 LDS image (18 x 34 used; row stride 56
+// halves = 28 dwords: conflict-free b128 reads); outputs channel-major ([c][16][32] f16, 8 bytes per lane) in their own LDS array.
+#include "fw_internal.h"
+#include "../../include/framewright_hip.h"
+
+namespace {
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+constexpr int CH = 32, ROWS = 18, RS = 56;                      // channels per launch tile (half a 64-channel chunk: the outputs get their own
+                                                                // LDS array here, so that hipcc need not order them against the next channel's reads), rows incl. halo, row stride
+
+__global__ __launch_bounds__(512, 1) void dw_mfma_kernel(const _Float16* __restrict__ y_in /* [CH][ROWS][RS] */,
+                                                          const unsigned* __restrict__ taps /* [CH][3 dy][2]: (w1 << 16 | w0), (w2) as f16 bits */,
+                                                          int iters, _Float16* out /* [CH][16][32] */, unsigned long long* clocks) {
+    __shared__ __attribute__((aligned(16))) _Float16 y[CH * ROWS * RS];      // 64.5 KB
+    __shared__ __attribute__((aligned(16))) _Float16 o[CH * 16 * 32];        // 32 KB, [channel][row][column]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane & 15, g = lane >> 4;
+    __shared__ __attribute__((aligned(8))) unsigned tl[CH * 6];     // the taps as (w1 | w0), (0 | w2) pairs per channel and tap row
+    for (int i = tid; i < CH * ROWS * RS / 8; i += 512) reinterpret_cast<uint4*>(y)[i] = reinterpret_cast<const uint4*>(y_in)[i];
+    if (tid < CH * 6) tl[tid] = taps[tid];
+    __syncthreads();
+    // per-lane byte selectors of the band: half j of this lane's A fragment (row m = q, k = 8 g + j) is tap d = k - m in {0, 1, 2} or 0
+    unsigned sel[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned s = 0;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int d = 8 * g + 2 * i + hh - q;
+            const unsigned pair = (d == 0) ? 0x0100u : (d == 1) ? 0x0302u : (d == 2) ? 0x0504u : 0x0706u;   // bytes of {S1 = (0, w2), S0 = (w1, w0)}
+            s |= pair << (16 * hh);
+        }
+        sel[i] = s;
+    }
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        // tap row outermost: the 8 accumulators of a wave (4 channels x 2 column halves) take one MFMA each per tap row, so no MFMA
+        // waits for the one before it (channel by channel, the three dependent MFMAs of an accumulator ran back to back: 2x slower)
+        f4 acc[CH / 8][2];
+#pragma unroll
+        for (int cc = 0; cc < CH / 8; ++cc) acc[cc][0] = acc[cc][1] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int cc = 0; cc < CH / 8; ++cc) {
+                const int c = wave * (CH / 8) + cc;
+                const uint2 tp2 = *reinterpret_cast<const uint2*>(tl + (c * 3 + dy) * 2);       // wave-uniform (LDS broadcast)
+                const uint4 A = make_uint4(__builtin_amdgcn_perm(tp2.y, tp2.x, sel[0]), __builtin_amdgcn_perm(tp2.y, tp2.x, sel[1]),
+                                           __builtin_amdgcn_perm(tp2.y, tp2.x, sel[2]), __builtin_amdgcn_perm(tp2.y, tp2.x, sel[3]));
+#pragma unroll
+                for (int xh = 0; xh < 2; ++xh) {
+#ifdef FW_DWM_NOREAD   // timing only: the B operand from registers
+                    const uint4 B = make_uint4(sel[0] + dy, sel[1] + xh, sel[2] + cc, sel[3]);
+#else
+                    const uint4 B = *reinterpret_cast<const uint4*>(y + (c * ROWS + q + dy) * RS + 16 * xh + 8 * g);
+#endif
+                    acc[cc][xh] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, A), __builtin_bit_cast(h8, B), acc[cc][xh], 0, 0, 0);
+                }
+            }
+        // D[m = 4 g + i][n = q]: four consecutive output columns of row q
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int cc = 0; cc < CH / 8; ++cc) {
+            const int c = wave * (CH / 8) + cc;
+#pragma unroll
+            for (int xh = 0; xh < 2; ++xh) {
+                const h4 r = {(_Float16)acc[cc][xh][0], (_Float16)acc[cc][xh][1], (_Float16)acc[cc][xh][2], (_Float16)acc[cc][xh][3]};
+#ifdef FW_DWM_NOWRITE  // timing only: one write per wave keeps the arithmetic alive
+                if (r[0] == (_Float16)123.25f) o[c] = r[1];
+#else
+                *reinterpret_cast<h4*>(o + (c * 16 + q) * 32 + 16 * xh + 4 * g) = r;
+#endif
+            }
+        }
+        __syncthreads();
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    for (int i = tid; i < CH * 16 * 32 / 8; i += 512) reinterpret_cast<uint4*>(out)[i] = reinterpret_cast<const uint4*>(o)[i];
+    if (tid == 0) atomicAdd(clocks, c1 - c0);
+}
+}  // namespace
+
+// y [64][18][56] f16 (host), taps [64][9] fp32 (host) -> out [64][16][32] f16 (host); cycles per chunk (all 64 channels of the tile, per
+// workgroup) in *cycles_out.  `blocks` workgroups run the same tile.
+extern "C" int fw_debug_dw_mfma(const uint16_t* y_host, const float* taps_host, int blocks, int iters, uint16_t* out_host, double* cycles_out) {
+    if (!y_host || !taps_host || !out_host || !cycles_out || blocks < 1 || iters < 1) return FW_ERR_INVALID;
+    _Float16 *y = nullptr, *o = nullptr;
+    unsigned* t = nullptr;
+    unsigned long long* clk = nullptr;
+    if (hipMalloc((void**)&y, CH * ROWS * RS * 2) != hipSuccess || hipMalloc((void**)&o, CH * 16 * 32 * 2) != hipSuccess ||
+        hipMalloc((void**)&t, CH * 6 * 4) != hipSuccess || hipMalloc((void**)&clk, 8) != hipSuccess)
+        return FW_ERR_OOM;
+    unsigned tp[CH * 6];
+    for (int c = 0; c < CH; ++c)
+        for (int dy = 0; dy < 3; ++dy) {
+            unsigned short w[3];
+            for (int d = 0; d < 3; ++d) {
+                const _Float16 hv = (_Float16)taps_host[c * 9 + dy * 3 + d];
+                memcpy(&w[d], &hv, 2);
+            }
+            tp[(c * 3 + dy) * 2] = (unsigned)w[0] | ((unsigned)w[1] << 16);
+            tp[(c * 3 + dy) * 2 + 1] = (unsigned)w[2];
+        }
+    (void)hipMemcpy(y, y_host, CH * ROWS * RS * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(t, tp, sizeof(tp), hipMemcpyHostToDevice);
+    for (int rep = 0; rep < 2; ++rep) {
+        (void)hipMemset(clk, 0, 8);
+        hipLaunchKernelGGL(dw_mfma_kernel, dim3(blocks), dim3(512), 0, nullptr, y, t, iters, o, clk);
+    }
+    const int rc = hipDeviceSynchronize() == hipSuccess ? FW_OK : FW_ERR_HIP;
+    unsigned long long c = 0;
+    (void)hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(out_host, o, CH * 16 * 32 * 2, hipMemcpyDeviceToHost);
+    *cycles_out = (double)c / blocks / iters;
+    (void)hipFree(y); (void)hipFree(o); (void)hipFree(t); (void)hipFree(clk);
+    return rc;
+}
