@@ -21,7 +21,8 @@ __global__ __launch_bounds__(512, 1) void dw_mfma_kernel(const _Float16* __restr
                                                           const unsigned* __restrict__ taps /* [CH][3 dy][2]: (w1 << 16 | w0), (w2) as f16 bits */,
                                                           int iters, _Float16* out /* [CH][16][32] */, unsigned long long* clocks) {
     __shared__ __attribute__((aligned(16))) _Float16 y[CH * ROWS * RS];      // 64.5 KB
-    __shared__ __attribute__((aligned(16))) _Float16 o[CH * 16 * 32];        // 32 KB, [channel][row][column]
+    constexpr int OS = 36;                                                   // output row stride in halves (32 + 4: 18 dwords, spreads the 8-byte writes over the banks)
+    __shared__ __attribute__((aligned(16))) _Float16 o[CH * 16 * OS];        // 36 KB, [channel][row][column]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane & 15, g = lane >> 4;
     __shared__ __attribute__((aligned(8))) unsigned tl[CH * 6];     // the taps as (w1 | w0), (0 | w2) pairs per channel and tap row
     for (int i = tid; i < CH * ROWS * RS / 8; i += 512) reinterpret_cast<uint4*>(y)[i] = reinterpret_cast<const uint4*>(y_in)[i];
@@ -40,6 +41,13 @@ __global__ __launch_bounds__(512, 1) void dw_mfma_kernel(const _Float16* __restr
         }
         sel[i] = s;
     }
+    // the wave's taps stay in registers (in a kernel they would be fetched a chunk ahead): read where they are used, each (channel, tap row)
+    // cost an LDS round trip in front of its A fragment - 12 per iteration, ~1500 of the first cut's cycles
+    uint2 tpr[CH / 8][3];
+#pragma unroll
+    for (int cc = 0; cc < CH / 8; ++cc)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) tpr[cc][dy] = *reinterpret_cast<const uint2*>(tl + ((wave * (CH / 8) + cc) * 3 + dy) * 2);
     const unsigned long long c0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
         // tap row outermost: the 8 accumulators of a wave (4 channels x 2 column halves) take one MFMA each per tap row, so no MFMA
@@ -52,7 +60,7 @@ __global__ __launch_bounds__(512, 1) void dw_mfma_kernel(const _Float16* __restr
 #pragma unroll
             for (int cc = 0; cc < CH / 8; ++cc) {
                 const int c = wave * (CH / 8) + cc;
-                const uint2 tp2 = *reinterpret_cast<const uint2*>(tl + (c * 3 + dy) * 2);       // wave-uniform (LDS broadcast)
+                const uint2 tp2 = tpr[cc][dy];
                 const uint4 A = make_uint4(__builtin_amdgcn_perm(tp2.y, tp2.x, sel[0]), __builtin_amdgcn_perm(tp2.y, tp2.x, sel[1]),
                                            __builtin_amdgcn_perm(tp2.y, tp2.x, sel[2]), __builtin_amdgcn_perm(tp2.y, tp2.x, sel[3]));
 #pragma unroll
@@ -76,14 +84,14 @@ __global__ __launch_bounds__(512, 1) void dw_mfma_kernel(const _Float16* __restr
 #ifdef FW_DWM_NOWRITE  // timing only: one write per wave keeps the arithmetic alive
                 if (r[0] == (_Float16)123.25f) o[c] = r[1];
 #else
-                *reinterpret_cast<h4*>(o + (c * 16 + q) * 32 + 16 * xh + 4 * g) = r;
+                *reinterpret_cast<h4*>(o + (c * 16 + q) * OS + 16 * xh + 4 * g) = r;
 #endif
             }
         }
         __syncthreads();
     }
     const unsigned long long c1 = __builtin_amdgcn_s_memtime();
-    for (int i = tid; i < CH * 16 * 32 / 8; i += 512) reinterpret_cast<uint4*>(out)[i] = reinterpret_cast<const uint4*>(o)[i];
+    for (int i = tid; i < CH * 16 * 32; i += 512) out[i] = o[(i >> 5) * OS + (i & 31)];
     if (tid == 0) atomicAdd(clocks, c1 - c0);
 }
 }  // namespace
