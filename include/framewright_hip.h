@@ -173,6 +173,18 @@ int fw_conv3x3_pair_nhwc(int dtype, const void* x, int in_cstride, long in_plane
                          int width, const void* packed_weight_a, const float* bias_a, const void* packed_weight_b,
                          const float* bias_b, void* out_a, void* out_b, int out_cstride, void* stream);
 
+/* lrelu(conv3x3(nearest_x2(x)) + bias), 64 -> 64 channels (conv_up1 / conv_up2, aesrgan_face.py:258-266) evaluated on the SOURCE
+ * grid as four 2x2 phase convolutions with summed weights: output pixel (2y + a, 2x + b) folds its three tap rows / columns onto two
+ * source rows / columns, 4 instead of 9 MFMA taps.  fw_pack_conv_up2x_phase packs a torch-layout weight [64][64][3][3] (host fp32;
+ * sums in fp64, rounded to the operand type once; returns the number of uint16, dst = NULL to size the buffer).
+ * x: operand-typed source image height x width, 64 channels as two 32-channel chunks in_plane_stride elements apart (0 = 32:
+ * interleaved NHWC with in_cstride channels per pixel); out: operand-typed [2*height][2*width][out_cstride], its two 32-channel
+ * halves out_plane_stride elements apart (0 = 32). */
+size_t fw_pack_conv_up2x_phase(int dtype, const float* weight, uint16_t* dst);
+int fw_conv_up2x_phase_nhwc(int dtype, const void* x, int in_cstride, long in_plane_stride, int height, int width,
+                            const void* packed_weight, const float* bias, int act_lrelu, void* out, int out_cstride,
+                            long out_plane_stride, void* stream);
+
 /* -------------------------------------------------------------------------------------------------
  * TAP temporal denoise: NAFNet
  * replaces  basicsr NAFNet construction + load in TAPDenoiser._load_nafnet (processors/tap_denoise.py:335-364),

@@ -76,3 +76,32 @@ def test_weight_packing_matches_fragment_map(hip_lib, dtype, cout, cin, ct, ch):
 def test_pack_rejects_bad_shapes(hip_lib):
     assert hip_lib.fw_pack_conv3x3(0, None, 65, 64, 2, 2, None) == 0
     assert hip_lib.fw_pack_conv3x3(0, None, 64, 65, 2, 2, None) == 0
+
+
+@pytest.mark.parametrize("dtype", [_lib.FW_DTYPE_BF16, _lib.FW_DTYPE_F16])
+def test_phase_weight_packing_matches_its_fragment_map(hip_lib, dtype):
+    """fw_pack_conv_up2x_phase: [row phase a][chunk c][step (tx, r, b) in use order][16-channel tile][lane][j] of the summed
+    2x2 phase kernels of nearest-x2 + conv3x3 (csrc/conv_up2x_phase.hip), sums in fp64, rounded once."""
+    import torch
+    rng = np.random.default_rng(7)
+    w = rng.standard_normal((64, 64, 3, 3)).astype(np.float32)
+    n = hip_lib.fw_pack_conv_up2x_phase(dtype, None, None)
+    assert n == 2 * 2 * 32 * 64 * 8
+    dst = np.zeros(n, np.uint16)
+    assert hip_lib.fw_pack_conv_up2x_phase(dtype, C.c_void_p(w.ctypes.data), C.c_void_p(dst.ctypes.data)) == n
+    assert hip_lib.fw_pack_conv_up2x_phase(7, None, None) == 0
+    fold = {0: ([0], [1, 2]), 1: ([0, 1], [2])}
+    steps = [(0, 0, 0), (0, 1, 0), (1, 0, 0), (1, 0, 1), (1, 1, 0), (1, 1, 1), (2, 0, 1), (2, 1, 1)]   # (tx, r, b); column tap = tx - b
+    want = np.empty((2, 2, 8, 4, 64, 8), np.uint16)
+    lane = np.arange(64)
+    tdt = torch.bfloat16 if dtype == _lib.FW_DTYPE_BF16 else torch.float16
+    for a in range(2):
+        for si, (tx, r, b) in enumerate(steps):
+            ws = w.astype(np.float64)[:, :, fold[a][r]][:, :, :, fold[b][tx - b]].sum(axis=(2, 3)).astype(np.float32)
+            bits = torch.from_numpy(ws).to(tdt).view(torch.int16).numpy().view(np.uint16)
+            for c in range(2):
+                for wt in range(4):
+                    co = 16 * wt + (lane & 15)
+                    for j in range(8):
+                        want[a, c, si, wt, :, j] = bits[co, 32 * c + 8 * (lane >> 4) + j]
+    np.testing.assert_array_equal(dst, want.reshape(-1))

@@ -123,6 +123,75 @@ def test_conv_upsample2x(hip_lib, dtype):
     assert (out_f32 - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
+def _phase_weights_ref(w):
+    """The four 2x2 phase kernels of nearest-x2 + conv3x3 (csrc/conv_up2x_phase.hip): phase 0 folds taps {0} / {1, 2} onto source
+    offsets 0 / 1, phase 1 folds {0, 1} / {2}.  Returns [a][b][cout][cin][2][2] in fp64."""
+    fold = {0: ([0], [1, 2]), 1: ([0, 1], [2])}
+    w = w.astype(np.float64)
+    out = np.zeros((2, 2) + w.shape[:2] + (2, 2))
+    for a in range(2):
+        for b in range(2):
+            for r in range(2):
+                for s in range(2):
+                    out[a, b, :, :, r, s] = w[:, :, fold[a][r]][:, :, :, fold[b][s]].sum(axis=(2, 3))
+    return out
+
+
+@pytest.mark.parametrize("dtype", [_lib.FW_DTYPE_BF16, _lib.FW_DTYPE_F16])
+@pytest.mark.parametrize("h,w_,planar", [
+    (16, 32, False),     # exactly one source tile
+    (13, 21, True),      # ragged, chunk-planar in and out (the RRDBNet tail's layout)
+    (1, 1, False),
+    (5, 3, True),
+    (33, 65, False),     # one row / column into the next tile
+    (368, 736, True),    # 529 source tiles: two or three per workgroup - the alternating chunk order and the refills between tiles
+])
+def test_conv_up2x_phase(hip_lib, dtype, h, w_, planar):
+    """conv_up1 / conv_up2 as four 2x2 phase convolutions == lrelu(conv3x3(nearest_x2(x))) (aesrgan_face.py:258-266)."""
+    rng = np.random.default_rng(h * 1000 + w_)
+    x = torch.from_numpy(rng.standard_normal((h, w_, 64)).astype(np.float32)).cuda().to(TDT[dtype])
+    w = (rng.standard_normal((64, 64, 3, 3)) / 24).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    n = hip_lib.fw_pack_conv_up2x_phase(dtype, None, None)
+    assert n == 2 * 2 * 32 * 64 * 8
+    pk = np.zeros(n, np.uint16)
+    assert hip_lib.fw_pack_conv_up2x_phase(dtype, C.c_void_p(w.ctypes.data), C.c_void_p(pk.ctypes.data)) == n
+    wp = torch.from_numpy(pk.view(np.int16)).cuda()
+    bias = torch.from_numpy(b).cuda()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    if planar:
+        xin = x.reshape(h, w_, 2, 32).permute(2, 0, 1, 3).contiguous()
+        out = torch.full((2, 2 * h, 2 * w_, 32), 7.0, dtype=TDT[dtype], device="cuda")
+        _lib.check(hip_lib.fw_conv_up2x_phase_nhwc(dtype, p(xin), 32, h * w_ * 32, h, w_, p(wp), p(bias), 1, p(out), 32, 4 * h * w_ * 32,
+                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        got = out.permute(1, 2, 0, 3).reshape(2 * h, 2 * w_, 64).float()
+    else:
+        out = torch.full((2 * h, 2 * w_, 64), 7.0, dtype=TDT[dtype], device="cuda")
+        _lib.check(hip_lib.fw_conv_up2x_phase_nhwc(dtype, p(x), 64, 0, h, w_, p(wp), p(bias), 1, p(out), 64, 0,
+                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        got = out.float()
+    # (1) against the same arithmetic in torch: the phase kernels with their ONCE-rounded summed weights, fp32 accumulation
+    wph = torch.from_numpy(_phase_weights_ref(w)).cuda().float().to(TDT[dtype]).float()
+    xs = x.float().permute(2, 0, 1).unsqueeze(0)
+    xp = F.pad(xs, (1, 1, 1, 1))
+    exact = torch.empty((2 * h, 2 * w_, 64), device="cuda")
+    for a in range(2):
+        for bb in range(2):
+            y = F.conv2d(xp[:, :, a:a + h + 1, bb:bb + w_ + 1], wph[a, bb], torch.from_numpy(b).cuda())
+            exact[a::2, bb::2] = F.leaky_relu(y, 0.2).squeeze(0).permute(1, 2, 0)
+    scale = max(1.0, exact.abs().max().item())
+    typed = exact.to(TDT[dtype]).float()
+    assert (got - typed).abs().max().item() <= (1.6e-2 if dtype == _lib.FW_DTYPE_BF16 else 2e-3) * scale   # one output rounding flip at most
+    assert (got - exact).abs().max().item() < (1.2e-2 if dtype == _lib.FW_DTYPE_BF16 else 1.5e-3) * scale
+    # (2) against the reference's formulation with fp32 weights: only operand rounding apart
+    wf = torch.from_numpy(w).cuda()
+    ref = F.leaky_relu(F.conv2d(F.interpolate(xs, scale_factor=2, mode="nearest"), wf, torch.from_numpy(b).cuda(), 1, 1), 0.2)
+    ref = ref.squeeze(0).permute(1, 2, 0)
+    assert (got - ref).abs().max().item() < (5e-2 if dtype == _lib.FW_DTYPE_BF16 else 6e-3) * scale
+
+
 @pytest.mark.parametrize("dtype", [_lib.FW_DTYPE_BF16, _lib.FW_DTYPE_F16])
 @pytest.mark.parametrize("two", [False, True])
 def test_conv_residual_epilogue(hip_lib, dtype, two):

@@ -28,7 +28,7 @@ EXPORTS = [
     "fw_nafnet_create", "fw_nafnet_set_tensor", "fw_nafnet_finalize", "fw_nafnet_denoise_u8", "fw_nafnet_flops",
     "fw_nafnet_destroy", "fw_u8_crop", "fw_tile_blend_accumulate", "fw_tile_blend_finish", "fw_temporal_average_u8",
     "fw_strength_blend_u8",
-    "fw_conv3x3_nhwc_ex", "fw_conv3x3_pair_nhwc", "fw_u8_to_rgb_f32", "fw_resize_bilinear_f32", "fw_ifnet_build_x", "fw_unshuffle2_cast",
+    "fw_conv3x3_nhwc_ex", "fw_conv3x3_pair_nhwc", "fw_pack_conv_up2x_phase", "fw_conv_up2x_phase_nhwc", "fw_u8_to_rgb_f32", "fw_resize_bilinear_f32", "fw_ifnet_build_x", "fw_unshuffle2_cast",
     "fw_depth_to_space4_f32", "fw_ifnet_accumulate", "fw_ifnet_blend", "fw_unsharp_mask_u8",
     "fw_ifnet_create", "fw_ifnet_set_tensor", "fw_ifnet_finalize", "fw_ifnet_interp_u8", "fw_ifnet_workspace_bytes", "fw_ifnet_flops",
     "fw_ifnet_destroy",
@@ -130,6 +130,10 @@ def _declare_ifnet(lib: C.CDLL) -> None:
     lib.fw_conv3x3_nhwc_ex.restype = i32
     lib.fw_conv3x3_nhwc_ex.argtypes = [i32, vp, i32, C.c_long, i32, i32, i32, vp, vp, i32, i32, i32, vp, f32, vp, f32, vp, i32,
                                        i32, i32, vp, i32, C.c_long, i32, vp, vp]
+    lib.fw_pack_conv_up2x_phase.restype = sz
+    lib.fw_pack_conv_up2x_phase.argtypes = [i32, vp, vp]
+    lib.fw_conv_up2x_phase_nhwc.restype = i32
+    lib.fw_conv_up2x_phase_nhwc.argtypes = [i32, vp, i32, C.c_long, i32, i32, vp, vp, i32, vp, i32, C.c_long, vp]
     lib.fw_conv3x3_pair_nhwc.restype = i32
     lib.fw_conv3x3_pair_nhwc.argtypes = [i32, vp, i32, C.c_long, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.fw_u8_to_rgb_f32.restype = i32

@@ -512,6 +512,8 @@ static int num_cus() {
     return n;
 }
 
+int conv_num_cus() { return num_cus(); }
+
 template <typename T>
 static void launch_typed(int cout_tiles, ConvEpilogue epi, const ConvParams& p, hipStream_t stream) {
     const int tiles = ((p.W + TILE_W - 1) / TILE_W) * ((p.H + TILE_H - 1) / TILE_H);

@@ -101,6 +101,25 @@ struct ConvPairParams {
 void launch_conv3x3_pair(DType dt, const ConvPairParams& p, hipStream_t stream);
 const void* conv_zero_page();  // 256 B of zeros on the current device
 
+// lrelu(conv3x3(nearest_x2(x)) + bias), 64 -> 64 channels, as four 2x2 phase convolutions on the source grid (conv_up2x_phase.hip)
+struct ConvUpParams {
+    const void* in;        // operand-typed SOURCE image, chunk c / pixel (y,x) at c*in_pstride + (y*W + x)*in_cstride; 2 chunks
+    int in_cstride;
+    long in_pstride;
+    int H, W;              // SOURCE size; the output is 2H x 2W
+    const void* wpk;       // pack_conv_up2x_phase_weights
+    const float* bias;     // [64]
+    int act;               // 1 = LeakyReLU(0.2)
+    void* out;             // typed [2H][2W][out_cstride]; the two 32-channel halves out_pstride elements apart (32 = interleaved)
+    int out_cstride;
+    long out_pstride;
+    const void* zeros;     // set by the launcher
+};
+void launch_conv_up2x_phase(DType dt, const ConvUpParams& p, hipStream_t stream);
+// w[64][64][3][3] fp32 -> the phase kernel's fragments (returns the number of uint16; dst may be null to query)
+size_t pack_conv_up2x_phase_weights(DType dt, const float* w, uint16_t* dst);
+int conv_num_cus();     // persistent workgroups per conv launch (CUs of the current device, FW_CONV_GRID)
+
 // Launches the kernel; cout_tiles in {1,2} (32 or 64 output channels).
 void launch_conv3x3(DType dt, int cout_tiles, ConvEpilogue epi, const ConvParams& p, hipStream_t stream);
 

@@ -22,6 +22,7 @@ struct ConvLayer {
     int cout = 0, cin = 0, ct = 0, chunks = 0;
     void* d_w = nullptr;
     float* d_b = nullptr;
+    void* d_wphase = nullptr;   // conv_up1 / conv_up2: the same weights as four 2x2 phase convolutions (conv_up2x_phase.hip)
     bool set = false;
 };
 
@@ -61,6 +62,9 @@ struct fw_rrdbnet {
     // plane, so their HBM reads collapse to about one plane at unchanged MACs: what a launch would cost if its inputs were
     // already on chip (FW_RRDB_ABL_ALIAS; DESIGN.md section 6 uses it to price fusions before building them)
     int abl_alias = 0;
+    // conv_up1 / conv_up2 (nearest x2 + 3x3) as four 2x2 phase convolutions on the source grid: 4 instead of 9 taps per output pixel
+    // (FW_RRDB_UP_PHASE=0 keeps the gathering nine-tap form, for A/B runs)
+    bool up_phase = true;
     // hipGraph capture of the per-frame forward (BASELINE configs[4] "hipGraph-captured per-frame stages").  graph_mode: 0 never
     // (default), 1 always, 2 for frames of at most graph_max_px input pixels.  Off by default because it buys nothing here: the
     // launches of a forward run back to back at 1080p, and even a 48x64 frame through 3 blocks takes 0.61 ms either way (the
@@ -199,6 +203,8 @@ ConvLayer* find_layer(fw_rrdbnet* n, const std::string& key, int* want_cout, int
 void free_layer(ConvLayer& l) {
     if (l.d_w) (void)hipFree(l.d_w);
     if (l.d_b) (void)hipFree(l.d_b);
+    if (l.d_wphase) (void)hipFree(l.d_wphase);
+    l.d_wphase = nullptr;
     l.d_w = nullptr;
     l.d_b = nullptr;
     l.set = false;
@@ -396,29 +402,49 @@ void forward(fw_rrdbnet* n, const void* d_in, int bits, int H, int W, void* d_ou
         cur = (cur + 1) % ncat;
     }
     // lrelu(conv_up1(nearest x2)), lrelu(conv_up2(nearest x2))                    (:260-266)
-    {
-        ConvParams p = base;
-        p.H = 2 * Ht;
-        p.W = 2 * Wt;
-        p.in = cat[cur];
-        p.upsample2x = 1;
-        p.out = U1;
-        p.out_pstride = 4 * PL;
-        p.act = 1;
-        run_conv(n, n->conv_up1, EPI_STORE, p, st);
-    }
-    {
-        ConvParams p = base;
-        p.H = 4 * Ht;
-        p.W = 4 * Wt;
-        p.in = U1;
-        p.in_pstride = 4 * PL;
-        p.upsample2x = 1;
-        p.out = U2;
-        p.out_pstride = 16 * PL;
-        p.act = 1;
-        run_conv(n, n->conv_up2, EPI_STORE, p, st);
-    }
+    auto run_up = [&](const ConvLayer& l, const void* src, long src_pstride, int Hs, int Ws, void* dst, long dst_pstride) {
+        if (n->up_phase && l.d_wphase) {
+            ConvUpParams u{};
+            u.in = src;
+            u.in_cstride = 32;
+            u.in_pstride = src_pstride;
+            u.H = Hs;
+            u.W = Ws;
+            u.wpk = l.d_wphase;
+            u.bias = l.d_b;
+            u.act = 1;
+            u.out = dst;
+            u.out_cstride = 32;
+            u.out_pstride = dst_pstride;
+            if (n->profile) {
+                if (n->ev_used + 2 > n->ev_pool.size()) {
+                    size_t old = n->ev_pool.size();
+                    n->ev_pool.resize(old + 1024);
+                    for (size_t i = old; i < n->ev_pool.size(); ++i) FW_HIP_CHECK(hipEventCreate(&n->ev_pool[i]));
+                }
+                FW_HIP_CHECK(hipEventRecord(n->ev_pool[n->ev_used++], st));
+                launch_conv_up2x_phase(n->dt, u, st);
+                FW_HIP_CHECK(hipEventRecord(n->ev_pool[n->ev_used++], st));
+                n->prof_flops += conv_flops(l, (size_t)4 * Hs * Ws);   // algorithmic: the nine-tap count of the reference's conv
+                n->prof_stream = st;
+            } else {
+                launch_conv_up2x_phase(n->dt, u, st);
+            }
+        } else {
+            ConvParams p = base;
+            p.H = 2 * Hs;
+            p.W = 2 * Ws;
+            p.in = src;
+            p.in_pstride = src_pstride;
+            p.upsample2x = 1;
+            p.out = dst;
+            p.out_pstride = dst_pstride;
+            p.act = 1;
+            run_conv(n, l, EPI_STORE, p, st);
+        }
+    };
+    run_up(n->conv_up1, cat[cur], PL, Ht, Wt, U1, 4 * PL);
+    run_up(n->conv_up2, U1, 4 * PL, 2 * Ht, 2 * Wt, U2, 16 * PL);
     // conv_last(lrelu(conv_hr(feat)))                                              (:268)
     {
         ConvParams p = base;
@@ -486,6 +512,7 @@ int fw_rrdbnet_create(int device_id, int num_block, int scale, int dtype, fw_rrd
         if (const char* e = getenv("FW_RRDB_SPLIT_TRUNK")) n->split_trunk = atoi(e) != 0;
         if (const char* e = getenv("FW_RRDB_LO")) n->rrdb_lo = atoi(e) != 0;
         if (const char* e = getenv("FW_RRDB_ABL_ALIAS")) n->abl_alias = atoi(e);
+        if (const char* e = getenv("FW_RRDB_UP_PHASE")) n->up_phase = atoi(e) != 0;
         *out = n.release();
     });
 }
@@ -516,6 +543,13 @@ int fw_rrdbnet_set_conv(fw_rrdbnet* n, const char* key, const float* weight, con
         FW_HIP_CHECK(hipMalloc((void**)&l->d_b, b.size() * 4));
         FW_HIP_CHECK(hipMemcpy(l->d_w, packed.data(), ne * 2, hipMemcpyHostToDevice));
         FW_HIP_CHECK(hipMemcpy(l->d_b, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+        if (l == &n->conv_up1 || l == &n->conv_up2) {
+            const size_t np = pack_conv_up2x_phase_weights(n->dt, nullptr, nullptr);
+            std::vector<uint16_t> ph(np);
+            pack_conv_up2x_phase_weights(n->dt, weight, ph.data());
+            FW_HIP_CHECK(hipMalloc(&l->d_wphase, np * 2));
+            FW_HIP_CHECK(hipMemcpy(l->d_wphase, ph.data(), np * 2, hipMemcpyHostToDevice));
+        }
         l->set = true;
     });
 }
@@ -788,6 +822,34 @@ int fw_conv3x3_nhwc_ex(int dtype, const void* x, int in_cstride, long in_plane_s
         p.f32_cstride = f32_cstride;
         p.f32_coff = f32_coff;
         launch_conv3x3((DType)dtype, cout_tiles, res1 ? EPI_RESIDUAL : EPI_STORE, p, (hipStream_t)stream);
+    });
+}
+
+size_t fw_pack_conv_up2x_phase(int dtype, const float* weight, uint16_t* dst) {
+    if (dtype != FW_DTYPE_BF16 && dtype != FW_DTYPE_F16) return 0;
+    if (dst && !weight) return 0;
+    return pack_conv_up2x_phase_weights((DType)dtype, weight, dst);
+}
+
+int fw_conv_up2x_phase_nhwc(int dtype, const void* x, int in_cstride, long in_plane_stride, int H, int W, const void* packed_weight,
+                            const float* bias, int act_lrelu, void* out, int out_cstride, long out_plane_stride, void* stream) {
+    if (!x || !packed_weight || !bias || !out) return fail(FW_ERR_INVALID, "fw_conv_up2x_phase_nhwc: NULL argument");
+    if (dtype != FW_DTYPE_BF16 && dtype != FW_DTYPE_F16) return fail(FW_ERR_INVALID, "fw_conv_up2x_phase_nhwc: bad dtype");
+    if (H < 1 || W < 1) return fail(FW_ERR_INVALID, "fw_conv_up2x_phase_nhwc: bad size");
+    return guarded([&] {
+        ConvUpParams u{};
+        u.in = x;
+        u.in_cstride = in_cstride;
+        u.in_pstride = in_plane_stride > 0 ? in_plane_stride : 32;
+        u.H = H;
+        u.W = W;
+        u.wpk = packed_weight;
+        u.bias = bias;
+        u.act = act_lrelu;
+        u.out = out;
+        u.out_cstride = out_cstride;
+        u.out_pstride = out_plane_stride > 0 ? out_plane_stride : 32;
+        launch_conv_up2x_phase((DType)dtype, u, (hipStream_t)stream);
     });
 }
 
