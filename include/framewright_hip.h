@@ -17,7 +17,10 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are asynchronous on
  *     that stream when every buffer is FW_DEVICE; calls with FW_HOST buffers return after the copy back.
  *   - one handle per GPU; calls on one handle are serialised by an internal mutex, so the reference's
- *     ThreadPoolExecutor callers (restorer.py:1894) may share a handle.
+ *     ThreadPoolExecutor callers (restorer.py:1894) may share a handle.  A handle owns ONE workspace: when two
+ *     FW_DEVICE calls on it are enqueued on different streams, the second stream waits (hipStreamWaitEvent) for an
+ *     event the first call recorded behind its last kernel, so the device work of a handle never overlaps whatever
+ *     the streams; callers that WANT two forwards in flight create one handle per stream.
  *   - images are H x W x 3 uint8 in BGR order (cv2 convention, plugins/base.py:186-250).
  */
 #ifndef FRAMEWRIGHT_HIP_H

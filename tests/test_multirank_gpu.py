@@ -79,3 +79,34 @@ def test_two_ranks_with_real_engines_equal_the_single_process_clip(hip_lib, n_fr
         assert np.array_equal(den[i], want_den[i]), f"denoised frame {i} differs across the rank boundary"
     for i in range(n_frames - 1):
         assert np.array_equal(mids[i], want_mid[i]), f"mid frame {i}"
+
+
+@pytest.mark.parametrize("config", ["sr", "tap", "rife", "chain"])
+def test_bench_two_ranks_under_torch_distributed_run(hip_lib, config, tmp_path):
+    """The command the driver uses for its scaling run, with two fresh ranks (`python -m torch.distributed.run ... bench.py --gpus 2`)
+    - both on the box's one card (FW_BENCH_FORCE_DEVICE=0: gloo rendezvous, halos as CPU tensors; on a node each rank has its own
+    GPU and the same branch moves device tensors over RCCL).  Must exit 0 and print ONE JSON line that says n_gpus 2; and
+    `--gpus 2` WITHOUT the launcher must refuse instead of measuring one GPU and reporting two."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, FW_BENCH_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    size = ["--height", "136", "--width", "240"] if config in ("sr", "chain") else ["--height", "270", "--width", "480"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--config", config, "--steps", "4", "--warmup", "1",
+           "--no-cpu-baseline", *size]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 4 and res["scaling"] == "weak" and res["value"] > 0
+    assert abs(res["value"] - 2 * 4 / (res["ms_per_step"] * 4 * 1e-3)) < 1e-6 * res["value"]      # whole-job rate: both ranks' frames over the slowest rank's time
+    if config == "sr":
+        r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True,
+                           timeout=300, cwd=str(root))
+        assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

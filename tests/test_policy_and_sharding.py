@@ -115,7 +115,11 @@ def test_block_partition_with_fewer_frames_than_ranks():
                 assert plans[0][1] == (0, 0) and plans[-1][2] == (0, 0)
 
 
-@pytest.mark.parametrize("n_frames,world,as_tensors", [(7, 2, False), (10, 2, False), (10, 2, True), (2, 4, False), (3, 4, True), (5, 3, False)])
+@pytest.mark.parametrize("n_frames,world,as_tensors", [
+    (7, 2, False), (10, 2, False), (10, 2, True), (2, 4, False), (3, 4, True), (5, 3, False),
+    # the node the driver's scaling run uses: eight ranks on the clip lengths of SURVEY section 8(d) (304 = 8 x 38 frames for the
+    # temporal denoise, 600 for the chain) and on a clip shorter than the world (ranks without frames post nothing and exit)
+    (304, 8, True), (600, 8, False), (5, 8, True)])
 def test_two_rank_sharding_equals_single_process(n_frames, world, as_tensors):
     rng = np.random.default_rng(n_frames)
     frames = [rng.integers(0, 256, size=(12, 16, 3), dtype=np.uint8) for _ in range(n_frames)]

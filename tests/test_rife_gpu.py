@@ -242,6 +242,27 @@ def test_pairs_in_flight_on_streams_equal_one_at_a_time(hip_lib):
     eng.close()
 
 
+def test_one_handle_on_several_streams_is_ordered_on_the_device(hip_lib):
+    """The C-ABI promise for a SHARED handle (include/framewright_hip.h, conventions): its mutex serialises the enqueue, and the one
+    workspace behind it is kept consistent across streams by an event recorded behind every forward that the next stream waits on
+    (fw_internal.h StreamOrder).  Eight forwards of one engine alternating over three streams with nothing synchronised in between
+    must give the frames the same forwards give on one stream - without the ordering two of them overwrite each other's workspace."""
+    fr = [torch.from_numpy(f).cuda() for f in synthetic_frames(5, 270, 480, seed=23)]
+    eng = RF.IFNetEngine("f16")
+    eng.load_state_dict(synthetic_ifnet_state())
+    pairs = [(fr[i % 4], fr[i % 4 + 1]) for i in range(8)]
+    want = [eng.interpolate_device(a, b, 0.5).clone() for a, b in pairs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs = [torch.empty_like(fr[0]) for _ in pairs]
+    for k, (a, b) in enumerate(pairs):
+        with torch.cuda.stream(streams[k % 3]):
+            eng.interpolate_device(a, b, 0.5, out=outs[k])
+    torch.cuda.synchronize()
+    assert all(torch.equal(g, w) for g, w in zip(outs, want))
+    eng.close()
+
+
 @pytest.mark.parametrize("H,W,gain,tol", [(70, 100, 1.0, 2e-4), (270, 480, 1.0, 2e-4), (270, 480, 12.0, 2e-3)])
 def test_fused_block_input_and_accumulate_equal_the_separate_kernels(hip_lib, monkeypatch, H, W, gain, tol):
     """An IFBlock's input as one kernel (build_x + both resizes + cat + pixel_unshuffle + cast) and lastconv's depth-to-space inside the

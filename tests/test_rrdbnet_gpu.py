@@ -10,6 +10,8 @@ Tolerances (stated on the [0,1] image range):
     operand rounding.
 """
 import math
+import threading
+import time
 
 import numpy as np
 import pytest
@@ -300,15 +302,16 @@ def test_baseline_config0_x2_on_eight_256x256_frames(hip_lib, tmp_path, monkeypa
     R.clear_upsampler_cache()
 
 
-@pytest.mark.parametrize("H,W,y0,x0", [(1080, 1920, 400, 800), (2160, 3840, 1900, 3500)])
-def test_full_size_properties_x4(hip_lib, H, W, y0, x0):
+@pytest.mark.parametrize("H,W,y0,x0,dtype", [(1080, 1920, 400, 800, "f16"), (1080, 1920, 400, 800, "bf16"), (2160, 3840, 1900, 3500, "f16")])
+def test_full_size_properties_x4(hip_lib, H, W, y0, x0, dtype):
     """BASELINE size (1920x1080 -> 7680x4320) and 4K (3840x2160 -> 15360x8640: 46 GB of workspace, byte offsets beyond
-    2^32), 6-block model to keep the test short: properties that need no oracle.
+    2^32), 6-block model to keep the test short: properties that need no oracle.  f16 is the benched operand type (bench.py,
+    every entry point's default); bf16 the opt-in one.
     (a) a crop far from the borders equals the same crop upscaled on its own with enough context (receptive field of
     the 6-block net + tail is < 100 px), (b) determinism."""
     nb = 6
     sd = synthetic_rrdbnet_state(nb, 4, seed=99)
-    eng = R.RRDBNetEngine(nb, 4, "bf16")
+    eng = R.RRDBNetEngine(nb, 4, dtype)
     eng.load_state_dict(sd)
     frame = synthetic_frames(1, H, W, seed=2)[0]
     t = torch.from_numpy(frame).cuda()
@@ -413,12 +416,13 @@ def test_hipgraph_capture_gives_identical_frames(hip_lib, monkeypatch):
     print(f"48x64 x4, 3 blocks: direct {outs['0'][1]:.3f} ms, graph {outs['1'][1]:.3f} ms")
 
 
-def test_sliding_window_pair_kernel_equals_ring_kernel_at_1080p(hip_lib, monkeypatch):
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_sliding_window_pair_kernel_equals_ring_kernel_at_1080p(hip_lib, monkeypatch, dtype):
     """Two independent implementations of the fused conv pair (conv3x3_pair_slide.hip, conv3x3_pair.hip) through the whole
     23-block x4 network on a BASELINE-size frame: every byte of the 7680x4320 output must agree (same per-pixel
     accumulation order)."""
     sd = synthetic_rrdbnet_state(23, 4, seed=1234)
-    eng = R.RRDBNetEngine(23, 4, "bf16")
+    eng = R.RRDBNetEngine(23, 4, dtype)      # f16: exactly the network, size and operand type bench.py times
     eng.load_state_dict(sd)
     d = torch.from_numpy(synthetic_frames(1, 1080, 1920, seed=2)[0]).cuda()
     outs = []
@@ -489,8 +493,43 @@ def test_thread_pool_on_one_shared_upsampler_with_an_injected_oom(hip_lib, tmp_p
     ok, err = R.enhance_frame_pytorch(tmp_path / "in_00.png", tmp_path / "again.png", cfg)
     assert ok and err is None
     assert np.array_equal(np.asarray(Image.open(tmp_path / "again.png"))[:, :, ::-1], serial[0])
-    # a closed engine refuses calls instead of touching freed memory
-    eng = R.get_upsampler(cfg).engine
+    # clearing the cache only drops it (pytorch_realesrgan.py:250-260): a worker that already holds the upsampler finishes its
+    # frames on it, the next get_upsampler builds a new one; an engine closed explicitly refuses calls instead of touching freed memory
+    held = R.get_upsampler(cfg)
     R.clear_upsampler_cache()
+    assert np.array_equal(held.enhance(frames[1], outscale=4)[0], serial[1])
+    fresh = R.get_upsampler(cfg)
+    assert fresh is not held and np.array_equal(fresh.enhance(frames[1], outscale=4)[0], serial[1])
+    eng = held.engine
+    eng.close()
     with pytest.raises(_lib.FramewrightHipError, match="closed"):
         eng.upscale(frames[0])
+    R.clear_upsampler_cache()
+
+    # one worker runs out of memory while its siblings are QUEUED on the shared upsampler's lock (they fetched it before the
+    # failing frame cleared the cache): every queued frame still comes back, from the object they hold
+    up = R.get_upsampler(cfg)
+    gate = threading.Event()
+    hit["n"] = 0
+
+    def oom_first(self, img, outscale=None, alpha_upsampler="realesrgan"):
+        hit["n"] += 1
+        if hit["n"] == 1:
+            gate.wait(5.0)                       # the siblings pile up behind this frame ...
+            raise _lib.FramewrightOutOfMemory(_lib.FW_ERR_OOM, "GPU out of memory: injected")
+        return real_enhance(self, img, outscale, alpha_upsampler)
+
+    monkeypatch.setattr(R.HipRealESRGANer, "enhance", oom_first)
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        futs = [ex.submit(job, i) for i in range(4)]
+        time.sleep(0.3)
+        gate.set()
+        results = dict(f.result() for f in futs)
+    assert sum(1 for ok, _ in results.values() if not ok) == 1
+    for i, (ok, err) in results.items():
+        if ok:
+            assert np.array_equal(np.asarray(Image.open(tmp_path / f"out_{i:02d}.png"))[:, :, ::-1], serial[i]), i
+        else:
+            assert "memory" in err.lower()
+    del up
+    R.clear_upsampler_cache()

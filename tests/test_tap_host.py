@@ -168,3 +168,33 @@ def test_grain_oracle_known_answers():
     assert int(blurred[4, 6]) == 80 and out[4, 6].tolist() == [62, 62, 62]
     assert np.array_equal(out[0, 0], den[0, 0])                                      # away from the spike: blurred >= gray
     assert tap_ref.bgr2gray_u8(np.array([[[255, 0, 0]]], np.uint8))[0, 0] == 29      # blue weight 1868 / 16384
+
+
+def test_restated_architectures_match_the_published_sizes():
+    """The third-party nets are absent (parity unpinned); the only upstream facts available offline are their published
+    sizes.  The shape tables the engines AND the oracles are built from must reproduce them with the constructor arguments the
+    reference passes (tap_denoise.py:340-346, :304-315): NAFNet-SIDD-width64 115.98 M parameters and 63.6 GMACs at 256 x 256
+    (NAFNet paper, table 1: convolutions; a profiler's count adds the element-wise ops), Restormer 26.13 M parameters."""
+    import re
+
+    import numpy as np
+
+    from framewright_amd.restormer import RESTORMER_ARGS, restormer_tensor_shapes
+    from framewright_amd.synth import nafnet_tensor_shapes
+    from framewright_amd.tap_denoise import NAFNET_ARGS
+
+    naf = nafnet_tensor_shapes(**NAFNET_ARGS)
+    assert abs(sum(int(np.prod(s)) for _, s in naf) / 1e6 - 115.98) < 0.005
+
+    def level(key):      # resolution level a tensor's convolution runs at (level l = 1 / 2^l of the frame)
+        for pat, f in ((r"encoders\.(\d+)\.", lambda i: i), (r"downs\.(\d+)\.", lambda i: i + 1), (r"ups\.(\d+)\.", lambda i: 4 - i),
+                       (r"decoders\.(\d+)\.", lambda i: 3 - i)):
+            m = re.match(pat, key)
+            if m:
+                return f(int(m.group(1)))
+        return 4 if key.startswith("middle_blks") else 0
+
+    macs = sum(int(np.prod(s)) * (1 if ".sca." in k else (256 >> level(k)) ** 2) for k, s in naf if k.endswith("weight") and len(s) == 4)
+    assert 63.0 < macs / 1e9 < 64.0, macs / 1e9          # 63.24 G in the convolutions; published 63.6
+    rest = restormer_tensor_shapes(**RESTORMER_ARGS)
+    assert abs(sum(int(np.prod(s)) for _, s in rest) / 1e6 - 26.13) < 0.005

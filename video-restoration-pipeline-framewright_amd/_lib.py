@@ -317,9 +317,24 @@ def on_tensor_device(fn):
             if isinstance(a, torch.Tensor) and a.is_cuda:
                 dev = a.device
                 break
-            if isinstance(a, (list, tuple)) and a and isinstance(a[0], torch.Tensor) and a[0].is_cuda:
-                dev = a[0].device
-                break
+            if isinstance(a, (list, tuple)):
+                t = next((x for x in a if isinstance(x, torch.Tensor) and x.is_cuda), None)   # any element: [None, tensor, ...] is a rank's block
+                if t is not None:
+                    dev = t.device
+                    break
+        if dev is None and args:
+            # no CUDA tensor among the arguments (numpy frames, None placeholders): the owner says where it lives -
+            # an engine's device (`_dev` / `device_id`) or a driver's `config.gpu_id`
+            owner = args[0]
+            cand = getattr(owner, "_dev", None)
+            if cand is None:
+                cand = getattr(owner, "device_id", None)
+            if cand is None:
+                cand = getattr(getattr(owner, "config", None), "gpu_id", None)
+            if isinstance(cand, torch.device):
+                dev = cand if cand.type == "cuda" else None
+            elif isinstance(cand, int) and not isinstance(cand, bool) and cand >= 0 and torch.cuda.is_available():
+                dev = torch.device("cuda", cand)
         if dev is None:
             return fn(*args, **kwargs)
         with torch.cuda.device(dev):

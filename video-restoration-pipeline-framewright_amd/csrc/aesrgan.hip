@@ -61,6 +61,7 @@ struct Arena {
 
 struct fw_aesrgan {
     int device = 0;
+    fw::StreamOrder order;   // device-side ordering of forwards enqueued on different streams (fw_internal.h)
     DType dt = DT_F16;
     int num_block = 23, scale = 2, num_attention = 4;
     std::mutex mu;
@@ -92,14 +93,6 @@ int guarded(F&& f) {
         return fail(FW_ERR_INTERNAL, e.what());
     }
 }
-struct DevGuard {
-    int prev = -1;
-    explicit DevGuard(int d) {
-        FW_HIP_CHECK(hipGetDevice(&prev));
-        if (prev != d) FW_HIP_CHECK(hipSetDevice(d)); else prev = -1;
-    }
-    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
-};
 void upload(DevBuf& b, const void* src, size_t bytes) {
     b.release();
     FW_HIP_CHECK(hipMalloc(&b.p, bytes));
@@ -366,6 +359,7 @@ int fw_aesrgan_forward_rgb(fw_aesrgan* n, const float* x_rgb, int H, int W, floa
         }
         Arena A;
         A.base = (char*)n->ws.p;
+        StreamOrder::Scope in_order(n->order, (hipStream_t)stream);
         forward(n, A, x_rgb, H, W, out_rgb, (hipStream_t)stream);
     });
 }
@@ -390,6 +384,7 @@ int fw_aesrgan_destroy(fw_aesrgan* n) {
     }
     n->ws.release();
     if (prev >= 0) (void)hipSetDevice(prev);
+    n->order.destroy();
     delete n;
     return FW_OK;
 }

@@ -872,7 +872,7 @@ __global__ __launch_bounds__(256) void pe_blend_kernel(const uint8_t* __restrict
 
 size_t preserve_edges_scratch_bytes(int H, int W) {
     const size_t n = (size_t)H * W;
-    return n * (4 + 2 + 1 + 4) + 256 + 64;
+    return n * (4 + 2 + 1 + 4) + 256 + 64 + 64;   // two alignment gaps (<= 255, <= 63 bytes) and the round flags
 }
 
 void launch_preserve_edges(const uint8_t* orig, const uint8_t* den, int H, int W, int lo, int hi, void* scratch, uint8_t* out,
@@ -888,14 +888,20 @@ void launch_preserve_edges(const uint8_t* orig, const uint8_t* den, int H, int W
     hipLaunchKernelGGL(pe_sobel_kernel, dim3(blocks), dim3(256), 0, st, orig, H, W, dxy, mag);
     hipLaunchKernelGGL(pe_nms_kernel, dim3(blocks), dim3(256), 0, st, dxy, mag, H, W, lo, hi, map);
     const int tiles = ((W + 31) / 32) * ((H + 31) / 32);
-    for (int round = 0; round < 4096; ++round) {   // a chain of weak pixels crosses at most this many tiles
-        FW_HIP_CHECK(hipMemsetAsync(changed, 0, 4, st));
-        hipLaunchKernelGGL(pe_hysteresis_kernel, dim3(tiles), dim3(256), 0, st, map, H, W, changed);
-        int flag = 0;
-        FW_HIP_CHECK(hipMemcpyAsync(&flag, changed, 4, hipMemcpyDeviceToHost, st));
+    // Global sweeps until no tile changed.  A chain of weak pixels that crosses T tiles needs T sweeps; almost every frame is done
+    // after one or two, so the sweeps go out four at a time behind ONE host round trip (a sweep over a converged map is a no-op
+    // that reports no change).  A map that has not converged after CAP sweeps is an error, not a silently wrong mask.
+    constexpr int BATCH = 4, CAP = 4096;
+    bool converged = false;
+    for (int round = 0; round < CAP && !converged; round += BATCH) {
+        FW_HIP_CHECK(hipMemsetAsync(changed, 0, BATCH * sizeof(int), st));
+        for (int b = 0; b < BATCH; ++b) hipLaunchKernelGGL(pe_hysteresis_kernel, dim3(tiles), dim3(256), 0, st, map, H, W, changed + b);
+        int flags[BATCH] = {};
+        FW_HIP_CHECK(hipMemcpyAsync(flags, changed, BATCH * sizeof(int), hipMemcpyDeviceToHost, st));
         FW_HIP_CHECK(hipStreamSynchronize(st));
-        if (!flag) break;
+        converged = flags[BATCH - 1] == 0;
     }
+    if (!converged) throw Error(4, "preserve_edges: the hysteresis did not reach its fixed point");
     hipLaunchKernelGGL(pe_mask_rows_kernel, dim3(blocks), dim3(256), 0, st, map, H, W, rows);
     hipLaunchKernelGGL(pe_blend_kernel, dim3(blocks), dim3(256), 0, st, orig, den, rows, H, W, out);
     FW_HIP_CHECK(hipGetLastError());

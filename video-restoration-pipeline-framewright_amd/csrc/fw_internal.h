@@ -325,6 +325,62 @@ struct Error : std::runtime_error {
         }                                                                                         \
     } while (0)
 
+// Makes `dev` the calling thread's current device for the scope of a C-ABI entry (one definition for every engine).
+struct DevGuard {
+    int prev = -1;
+    explicit DevGuard(int dev) {
+        FW_HIP_CHECK(hipGetDevice(&prev));
+        if (prev != dev) FW_HIP_CHECK(hipSetDevice(dev));
+        else prev = -1;
+    }
+    ~DevGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DevGuard(const DevGuard&) = delete;
+    DevGuard& operator=(const DevGuard&) = delete;
+};
+
+// One engine handle = one workspace arena, but its callers may enqueue on different streams (thread-pool callers with a stream
+// each, include/framewright_hip.h).  The handle's mutex serialises the ENQUEUE only; this orders the device work: every forward
+// records an event behind its last launch, and a forward enqueued on another stream first waits for that event - the workspace is
+// never written by two forwards at once.  Same stream: stream order already does it, no wait is inserted.
+struct StreamOrder {
+    hipEvent_t ev = nullptr;
+    hipStream_t last = nullptr;
+    bool have = false;
+    struct Scope {
+        StreamOrder& o;
+        hipStream_t st;
+        Scope(StreamOrder& order, hipStream_t stream) : o(order), st(stream) {
+            if (o.have && o.last != st) FW_HIP_CHECK(hipStreamWaitEvent(st, o.ev, 0));
+        }
+        ~Scope() {
+            if (!o.ev && hipEventCreateWithFlags(&o.ev, hipEventDisableTiming) != hipSuccess) {
+                o.ev = nullptr;
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(st);   // no event to be had: fall back to a host wait, never to an unordered workspace
+                o.have = false;
+                return;
+            }
+            if (hipEventRecord(o.ev, st) == hipSuccess) {
+                o.last = st;
+                o.have = true;
+            } else {
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(st);
+                o.have = false;
+            }
+        }
+        Scope(const Scope&) = delete;
+        Scope& operator=(const Scope&) = delete;
+    };
+    void destroy() {
+        if (ev) (void)hipEventDestroy(ev);
+        ev = nullptr;
+        have = false;
+    }
+};
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // GELU (exact form, 0.5 x (1 + erf(x / sqrt 2))) of two values, erf after Abramowitz & Stegun 7.1.28:
 //   erf(z) = 1 - 1 / (1 + a1 z + ... + a6 z^6)^16,  z >= 0, |error| <= 3e-7 (7e-7 on the GELU in fp32, against scipy on [-12, 12])

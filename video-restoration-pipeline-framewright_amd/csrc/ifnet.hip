@@ -171,6 +171,7 @@ struct Plan {
 
 struct fw_ifnet {
     int device = 0;
+    fw::StreamOrder order;   // device-side ordering of forwards enqueued on different streams (fw_internal.h)
     DType dt = DT_F16;
     std::mutex mu;
     Block blk[NBLK];
@@ -215,15 +216,6 @@ int guarded(F&& f) {
         return fail(FW_ERR_INTERNAL, e.what());
     }
 }
-
-struct DevGuard {
-    int prev = -1;
-    explicit DevGuard(int d) {
-        FW_HIP_CHECK(hipGetDevice(&prev));
-        if (prev != d) FW_HIP_CHECK(hipSetDevice(d)); else prev = -1;
-    }
-    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
-};
 
 size_t esz(DType) { return 2; }
 
@@ -531,6 +523,7 @@ int fw_ifnet_interp_u8(fw_ifnet* n, const uint8_t* frame0, const uint8_t* frame1
         std::lock_guard<std::mutex> lk(n->mu);
         DevGuard dg(n->device);
         hipStream_t st = (hipStream_t)stream;
+        StreamOrder::Scope in_order(n->order, st);
         const Plan pl = make_plan(H, W);
         if (n->ws.bytes < pl.total) {
             FW_HIP_CHECK(hipDeviceSynchronize());
@@ -614,6 +607,7 @@ int fw_ifnet_destroy(fw_ifnet* n) {
     }
     n->ws.release();
     if (prev >= 0) (void)hipSetDevice(prev);
+    n->order.destroy();
     delete n;
     return FW_OK;
 }

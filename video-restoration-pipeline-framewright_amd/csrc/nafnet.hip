@@ -56,6 +56,7 @@ struct Level {
 
 struct fw_nafnet {
     int device = 0;
+    fw::StreamOrder order;   // device-side ordering of forwards enqueued on different streams (fw_internal.h)
     DType dt = DT_BF16;
     int width = 64, middle = 12;
     int nlev = 4;
@@ -104,15 +105,6 @@ int guarded(F&& f) {
         return fail(FW_ERR_INTERNAL, e.what());
     }
 }
-
-struct DevGuard {
-    int prev = -1;
-    explicit DevGuard(int d) {
-        FW_HIP_CHECK(hipGetDevice(&prev));
-        if (prev != d) FW_HIP_CHECK(hipSetDevice(d)); else prev = -1;
-    }
-    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
-};
 
 void drop_graphs(fw_nafnet* n) {
     for (auto& g : n->graphs) {
@@ -537,6 +529,7 @@ int fw_nafnet_denoise_u8(fw_nafnet* n, const uint8_t* in_bgr, int in_loc, int H,
         std::lock_guard<std::mutex> lk(n->mu);
         DevGuard dg(n->device);
         hipStream_t st = (hipStream_t)stream;
+        StreamOrder::Scope in_order(n->order, st);
         const Plan pl = make_plan(n, H, W);
         if (n->ws.bytes < pl.total) {
             FW_HIP_CHECK(hipDeviceSynchronize());
@@ -705,6 +698,7 @@ int fw_nafnet_destroy(fw_nafnet* n) {
     n->intro_w.release(); n->intro_b.release(); n->ending_w.release(); n->ending_b.release();
     n->ws.release();
     if (prev >= 0) (void)hipSetDevice(prev);
+    n->order.destroy();
     delete n;
     return FW_OK;
 }

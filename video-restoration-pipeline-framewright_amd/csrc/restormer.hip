@@ -132,6 +132,7 @@ struct Arena {
 
 struct fw_restormer {
     int device = 0;
+    fw::StreamOrder order;   // device-side ordering of forwards enqueued on different streams (fw_internal.h)
     DType dt = DT_F16;
     int dim = 48, nblk[4] = {4, 6, 6, 8}, nref = 4, heads[4] = {1, 2, 4, 8};
     double ffn = 2.66;
@@ -171,15 +172,6 @@ int guarded(F&& f) {
         return fail(FW_ERR_INTERNAL, e.what());
     }
 }
-
-struct DevGuard {
-    int prev = -1;
-    explicit DevGuard(int d) {
-        FW_HIP_CHECK(hipGetDevice(&prev));
-        if (prev != d) FW_HIP_CHECK(hipSetDevice(d)); else prev = -1;
-    }
-    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
-};
 
 // a building block failed: its message is already in fw_last_error()
 void chk(int status) {
@@ -583,6 +575,7 @@ int fw_restormer_denoise_u8(fw_restormer* n, const uint8_t* in_bgr, int in_loc, 
         std::lock_guard<std::mutex> lk(n->mu);
         DevGuard dg(n->device);
         hipStream_t st = (hipStream_t)stream;
+        StreamOrder::Scope in_order(n->order, st);
         const size_t frame = ((size_t)H * W * 3 + 255) / 256 * 256;
         Arena P;
         P.plan = true;
@@ -623,6 +616,7 @@ int fw_restormer_destroy(fw_restormer* n) {
     for (auto& kv : n->convs) kv.second.release();
     for (DevBuf* b : {&n->red3, &n->red2, &n->conv_bias, &n->ones, &n->ws}) b->release();
     if (prev >= 0) (void)hipSetDevice(prev);
+    n->order.destroy();
     delete n;
     return FW_OK;
 }

@@ -44,6 +44,7 @@ std::string& last_error_ref() {
 
 struct fw_rrdbnet {
     int device = 0;
+    fw::StreamOrder order;   // device-side ordering of forwards enqueued on different streams (fw_internal.h)
     int num_block = 0;
     int scale = 4;
     DType dt = DT_BF16;
@@ -111,18 +112,6 @@ int guarded(F&& f) {
         return fail(FW_ERR_INTERNAL, e.what());
     }
 }
-
-struct DeviceGuard {
-    int prev = -1;
-    explicit DeviceGuard(int dev) {
-        FW_HIP_CHECK(hipGetDevice(&prev));
-        if (prev != dev) FW_HIP_CHECK(hipSetDevice(dev));
-        else prev = -1;
-    }
-    ~DeviceGuard() {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -528,7 +517,7 @@ int fw_rrdbnet_set_conv(fw_rrdbnet* n, const char* key, const float* weight, con
             throw Error(FW_ERR_INVALID, std::string("fw_rrdbnet_set_conv: shape mismatch for '") + key + "': got [" +
                                             std::to_string(cout) + "," + std::to_string(cin) + ",3,3], expected [" +
                                             std::to_string(wco) + "," + std::to_string(wci) + ",3,3]");
-        DeviceGuard dg(n->device);
+        DevGuard dg(n->device);
         free_layer(*l);
         l->cout = cout;
         l->cin = cin;
@@ -609,8 +598,9 @@ static int upscale_any(fw_rrdbnet* n, const void* in_bgr, int in_loc, int bits, 
     if (rc != FW_OK) return rc;
     return guarded([&] {
         std::lock_guard<std::mutex> lk(n->mu);
-        DeviceGuard dg(n->device);
+        DevGuard dg(n->device);
         hipStream_t st = (hipStream_t)stream;
+        StreamOrder::Scope in_order(n->order, st);
         const Plan pl = make_plan(n, H, W);
         if (n->ws.bytes < pl.total) {
             // the previous workspace may still be in use by work queued on some stream
@@ -704,7 +694,7 @@ int fw_rrdbnet_profile_read(fw_rrdbnet* n, int* launches, double* total_ms, doub
     if (!n) return fail(FW_ERR_INVALID, "fw_rrdbnet_profile_read: NULL");
     return guarded([&] {
         std::lock_guard<std::mutex> lk(n->mu);
-        DeviceGuard dg(n->device);
+        DevGuard dg(n->device);
         double ms = 0;
         if (n->ev_used) FW_HIP_CHECK(hipEventSynchronize(n->ev_pool[n->ev_used - 1]));
         for (size_t i = 0; i + 1 < n->ev_used; i += 2) {
@@ -740,6 +730,7 @@ int fw_rrdbnet_destroy(fw_rrdbnet* n) {
     if (n->ws.base) (void)hipFree(n->ws.base);
     for (auto e : n->ev_pool) (void)hipEventDestroy(e);
     if (prev >= 0) (void)hipSetDevice(prev);
+    n->order.destroy();
     delete n;
     return FW_OK;
 }

@@ -44,6 +44,7 @@ struct Layer {
 
 struct fw_srvgg {
     int device = 0;
+    fw::StreamOrder order;   // device-side ordering of forwards enqueued on different streams (fw_internal.h)
     DType dt = DT_F16;
     int num_feat = 64, num_conv = 16, scale = 4;
     std::mutex mu;
@@ -71,15 +72,6 @@ int guarded(F&& f) {
         return fail(FW_ERR_INTERNAL, e.what());
     }
 }
-
-struct DevGuard {
-    int prev = -1;
-    explicit DevGuard(int d) {
-        FW_HIP_CHECK(hipGetDevice(&prev));
-        if (prev != d) FW_HIP_CHECK(hipSetDevice(d)); else prev = -1;
-    }
-    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
-};
 
 void upload(DevBuf& b, const void* src, size_t bytes) {
     b.release();
@@ -249,6 +241,7 @@ int upscale_any(fw_srvgg* n, const void* in_bgr, int bits, int in_loc, int H, in
         std::lock_guard<std::mutex> lk(n->mu);
         DevGuard dg(n->device);
         hipStream_t st = (hipStream_t)stream;
+        StreamOrder::Scope in_order(n->order, st);
         const Plan pl = make_plan(n, H, W);
         if (n->ws.bytes < pl.total) {
             FW_HIP_CHECK(hipDeviceSynchronize());
@@ -298,6 +291,7 @@ int fw_srvgg_destroy(fw_srvgg* n) {
     }
     n->ws.release();
     if (prev >= 0) (void)hipSetDevice(prev);
+    n->order.destroy();
     delete n;
     return FW_OK;
 }

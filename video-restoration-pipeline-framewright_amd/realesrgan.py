@@ -504,13 +504,15 @@ def enhance_frame_pytorch(input_path: Path, output_path: Path, config: PyTorchES
 
 
 def clear_upsampler_cache() -> None:
-    """pytorch_realesrgan.py:250-260."""
+    """pytorch_realesrgan.py:250-260: `_UPSAMPLER = None` + `torch.cuda.empty_cache()`.  Like the reference this only DROPS the
+    cache entries: a worker of the thread pool (restorer.py:1830-1973) that already holds the upsampler - queued on its lock while a
+    sibling's frame ran out of memory - finishes its frame on the old object, and the native engine is destroyed when the last
+    reference to it goes away (RRDBNetEngine.__del__ -> close()).  Round 2 closed the engines here, which failed those queued
+    frames with "the engine has been closed" although they would have succeeded."""
     with _UPSAMPLER_LOCK:
         ups = list(_UPSAMPLERS.values())
         _UPSAMPLERS.clear()
-    for up in ups:
-        with up._mu:            # a sibling worker's enhance() in flight finishes first (restorer.py:1830-1973 thread pool)
-            up.engine.close()
+    del ups          # engines nobody else holds are destroyed here, their device memory returned
 
 
 NCNN_TO_PYTORCH_MODEL = {
