@@ -263,7 +263,10 @@ def main():
             run_pass(k)
             done += k
 
-    run_steps(max(1, args.warmup))
+    warm = max(1, args.warmup)
+    if cfg in ("tap", "chain") and world > 1:
+        warm = max(warm, 2)        # a block holds at least window // 2 frames, in the warm-up pass too
+    run_steps(warm)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()

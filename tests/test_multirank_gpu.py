@@ -100,7 +100,7 @@ def test_bench_two_ranks_under_torch_distributed_run(hip_lib, config, tmp_path):
            "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--config", config, "--steps", "4", "--warmup", "1",
            "--no-cpu-baseline", *size]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(root))
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, "\n".join(ln for ln in r.stderr.splitlines() if "socket.cpp" not in ln and "amdgpu.ids" not in ln)[-6000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     res = json.loads(lines[0])

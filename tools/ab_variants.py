@@ -30,14 +30,33 @@ torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / N * 1e3
 eng.profile_enable(True)
 for _ in range(2): eng.upscale_device(d, out=o)
 launches, conv_ms, conv_flops = eng.profile_read()
-print(json.dumps({"ms_per_frame": ms, "conv_tflops": conv_flops / conv_ms / 1e9, "checksum": int(o[::97, ::89].to(torch.int64).sum())}))
+up = {}
+if os.environ.get("FW_AB_TIME_UP"):
+    import ctypes as C, numpy as np
+    from framewright_amd import _lib
+    lib = _lib.load()
+    w = (np.random.default_rng(0).standard_normal((64, 64, 3, 3)) / 24).astype(np.float32)
+    n = lib.fw_pack_conv_up2x_phase(1, None, None); pk = np.zeros(n, np.uint16)
+    lib.fw_pack_conv_up2x_phase(1, C.c_void_p(w.ctypes.data), C.c_void_p(pk.ctypes.data))
+    wp = torch.from_numpy(pk.view(np.int16)).cuda(); bias = torch.zeros(64, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    for nm, (h, w_) in {"up1": (1080, 1920), "up2": (2160, 3840)}.items():
+        x = torch.randn((2, h, w_, 32), device="cuda").half(); out = torch.empty((2, 2 * h, 2 * w_, 32), dtype=torch.float16, device="cuda")
+        run = lambda: _lib.check(lib.fw_conv_up2x_phase_nhwc(1, p(x), 32, h * w_ * 32, h, w_, p(wp), p(bias), 1, p(out), 32, 4 * h * w_ * 32, None))
+        run(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): run()
+        e1.record(); torch.cuda.synchronize()
+        up[nm + "_ms"] = e0.elapsed_time(e1) / 20
+print(json.dumps({"ms_per_frame": ms, "conv_tflops": conv_flops / conv_ms / 1e9, "checksum": int(o[::97, ::89].to(torch.int64).sum()), **up}))
 """
 
 
 def rebuild(srcdir: Path, flags: list[str]) -> None:
     cc = B.hipcc()
     B.build()  # the other objects
-    for name in ("conv3x3_mfma", "conv3x3_pair", "conv3x3_pair_slide"):
+    for name in ("conv3x3_mfma", "conv3x3_pair", "conv3x3_pair_slide", "conv_up2x_phase"):
         src = srcdir / f"{name}.hip"
         if not src.exists():
             src = B.CSRC / f"{name}.hip"

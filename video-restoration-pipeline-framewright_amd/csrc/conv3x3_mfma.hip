@@ -257,6 +257,33 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
             const bool do_w = n + 1 < nitems && !(dbg & 2);
             const bool do_a = n + NA - 1 < nitems && !(dbg & 2);
             const int c1 = (c + 1 == nch) ? 0 : c + 1;
+            // SPLIT: residual plane c (c < n_id) goes straight from HBM to B-fragment registers - lane (pixel 16*ph + q, slot sl) takes
+            // 8 channels of its two rows' pixels - consumed after the item's MFMAs: no LDS, no halo.  The loads go out from slot
+            // FW_RES_SLOT of the item, BEHIND its two DMA batches (slots FW_DMA_SLOT_W / _A): hipcc waits for its own loads with
+            // vmcnt(0), which also sits out every LDS-DMA issued after them - issued at the top of the item (round 2) that wait
+            // drained the prefetch of the next item at the end of every residual item (rdb3's conv5: 4 of 6 items; 3.4 ms per frame,
+            // gpurun_out/r03/ab4.log); issued last, the DMAs in front of them have had the item's MFMAs to land.
+            uint4 idx[RPW][2];
+            const bool has_id = SPLIT && c < p.n_id;
+            auto load_residual = [&]() {
+                if constexpr (SPLIT) {
+                    if (has_id) {
+                        const char* plane = reinterpret_cast<const char*>(p.in) + p.chunk_off[c];
+#pragma unroll
+                        for (int row = 0; row < RPW; ++row)
+#pragma unroll
+                            for (int ph = 0; ph < 2; ++ph) {
+                                const int y = y0 + RPW * wave + row, x = x0 + 16 * ph + q;
+                                {
+                                    // outside the image: the zero page (a select on the loaded VALUE would wait for the load here)
+                                    const char* px = (y < p.H && x < p.W) ? plane + (((size_t)y * p.W + x) * p.in_cstride + 8 * sl) * 2
+                                                                          : reinterpret_cast<const char*>(p.zeros);
+                                    idx[row][ph] = *reinterpret_cast<const uint4*>(px);
+                                }
+                            }
+                    }
+                }
+            };
             // The two DMA batches of this boundary (weights of item n+1, activations of item n+NA-1) go out in the shadow
             // of the first MFMAs: slot d of 36, compile-time after unrolling.
 #ifndef FW_DMA_SLOT_W
@@ -268,11 +295,16 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
 #define FW_DMA_SLOT_A2 FW_DMA_SLOT_A
 #endif
             const bool young = wave >= NWAVES / 2;
+#ifndef FW_RES_SLOT
+#define FW_RES_SLOT 20
+#endif
             auto dma_slot = [&](int d) {
                 if (d == (young ? FW_DMA_SLOT_W2 : FW_DMA_SLOT_W)) {
                     if (do_w) issue_w(c1, (n + 1) & 1);
                 } else if (d == (young ? FW_DMA_SLOT_A2 : FW_DMA_SLOT_A)) {
                     if (do_a) issue_act();
+                } else if (d == FW_RES_SLOT) {
+                    load_residual();
                 }
             };
 
@@ -281,23 +313,6 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
             // SPLIT: residual plane c (c < n_id) goes straight from HBM to B-fragment registers - lane (pixel 16*ph + q,
             // slot sl) takes 8 channels of its two rows' pixels - issued now, consumed after the item's MFMAs: no LDS, no
             // halo, and the latency hides under the item.
-            uint4 idx[RPW][2];
-            const bool has_id = SPLIT && c < p.n_id;
-            if constexpr (SPLIT) {
-                if (has_id) {
-                    const char* plane = reinterpret_cast<const char*>(p.in) + p.chunk_off[c];
-#pragma unroll
-                    for (int row = 0; row < RPW; ++row)
-#pragma unroll
-                        for (int ph = 0; ph < 2; ++ph) {
-                            const int y = y0 + RPW * wave + row, x = x0 + 16 * ph + q;
-                            // outside the image: the zero page (a select on the loaded VALUE would wait for the load here)
-                            const char* px = (y < p.H && x < p.W) ? plane + (((size_t)y * p.W + x) * p.in_cstride + 8 * sl) * 2
-                                                                  : reinterpret_cast<const char*>(p.zeros);
-                            idx[row][ph] = *reinterpret_cast<const uint4*>(px);
-                        }
-                }
-            }
             auto& slot_fn = dma_slot;
             conv_item<T, NW, 0>(
                 acc, a, wl, rd_off, [](int tap, int w) { return tap * NW + w; }, slot_fn,
@@ -310,7 +325,9 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
                 [](int) {});
             FW_STAMP(1);  // item compute
             if constexpr (SPLIT) {
-                if (has_id) add_identity(idx, p.id_scale[c], c & 1);
+                if (has_id) {
+                    add_identity(idx, p.id_scale[c], c & 1);
+                }
             }
             FW_STAMP(2);  // residual plane: wait for its loads + 8 identity MFMAs
         }

@@ -30,6 +30,9 @@
 #define FW_UP_SLOT_W 2
 #define FW_UP_SLOT_A 6
 #endif
+#ifndef FW_UP_FULL_LINES
+#define FW_UP_FULL_LINES 1
+#endif
 
 namespace fw {
 
@@ -186,7 +189,10 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv_up2x_phase_k
     const int ls = (sl & 1) ? 2 + (sl >> 1) : (sl >> 1);   // the 8-channel slot this lane holds after the permlane swap
     const long Wout = 2L * p.W;
     char* outb = reinterpret_cast<char*>(p.out);
-    const unsigned lane_off = (unsigned)((2 * q * p.out_cstride + ls * 8) * 2);
+    [[maybe_unused]] const unsigned lane_off = (unsigned)((2 * q * p.out_cstride + ls * 8) * 2);
+    const bool odd = (q & 1) != 0;
+    const unsigned lane_off1 = (unsigned)(((odd ? 2 * q - 1 : 2 * q) * p.out_cstride + ls * 8) * 2);       // FW_UP_FULL_LINES: pixels 4k / 4k + 1
+    const unsigned lane_off2 = (unsigned)(((odd ? 2 * q + 1 : 2 * q + 2) * p.out_cstride + ls * 8) * 2);   //                   pixels 4k + 2 / 4k + 3
 
     issue_w(0, 0, 0);
     issue_act(t_lo, 0);
@@ -247,7 +253,8 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv_up2x_phase_k
 #pragma unroll
                     for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
-                        for (int c2 = 0; c2 < 2; ++c2)
+                        for (int c2 = 0; c2 < 2; ++c2) {
+                            uint4 v[2];
 #pragma unroll
                             for (int b = 0; b < 2; ++b) {
                                 f32x4 oa = acc[row][4 * b + 2 * c2][ph], ob = acc[row][4 * b + 2 * c2 + 1][ph];
@@ -259,10 +266,31 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv_up2x_phase_k
                                 const uint2 pb = Op<T>::pack4(ob[0], ob[1], ob[2], ob[3]);
                                 const u32x2 sx = __builtin_amdgcn_permlane16_swap(pa.x, pb.x, false, false);
                                 const u32x2 sy = __builtin_amdgcn_permlane16_swap(pa.y, pb.y, false, false);
-                                if (x0 + 16 * ph + q < p.W)
-                                    store16(rowbase + (long)c2 * p.out_pstride * 2 + (long)(32 * ph + b) * p.out_cstride * 2 + lane_off,
-                                            make_uint4(sx[0], sy[0], sx[1], sy[1]));
+                                v[b] = make_uint4(sx[0], sy[0], sx[1], sy[1]);
                             }
+                            char* base = rowbase + (long)c2 * p.out_pstride * 2 + (long)(32 * ph) * p.out_cstride * 2;
+#if FW_UP_FULL_LINES
+                            // A lane holds its slot of output pixels 2x (v[0]) and 2x + 1 (v[1]); stored as they stand, every store
+                            // instruction writes 64-byte halves of 16 lines.  Neighbouring lanes x, x ^ 1 trade one of the two
+                            // (quad-permute DPP, no LDS): the first store then covers pixels 4k, 4k + 1 and the second 4k + 2,
+                            // 4k + 3 - whole 128-byte lines from 8 lanes each.
+                            const uint4 snd = odd ? v[0] : v[1];
+                            uint4 rcv;
+                            rcv.x = (unsigned)__builtin_amdgcn_mov_dpp((int)snd.x, 0xB1, 0xF, 0xF, true);
+                            rcv.y = (unsigned)__builtin_amdgcn_mov_dpp((int)snd.y, 0xB1, 0xF, 0xF, true);
+                            rcv.z = (unsigned)__builtin_amdgcn_mov_dpp((int)snd.z, 0xB1, 0xF, 0xF, true);
+                            rcv.w = (unsigned)__builtin_amdgcn_mov_dpp((int)snd.w, 0xB1, 0xF, 0xF, true);
+                            const int xs = x0 + 16 * ph + q;                 // this lane's source pixel; the neighbour's is xs ^ 1
+                            const bool own_ok = xs < p.W, nb_ok = (xs ^ 1) < p.W;
+                            if (odd ? nb_ok : own_ok) store16(base + lane_off1, odd ? rcv : v[0]);
+                            if (odd ? own_ok : nb_ok) store16(base + lane_off2, odd ? v[1] : rcv);
+#else
+                            if (x0 + 16 * ph + q < p.W) {
+                                store16(base + lane_off, v[0]);
+                                store16(base + (long)p.out_cstride * 2 + lane_off, v[1]);
+                            }
+#endif
+                        }
                 }
             }
         }

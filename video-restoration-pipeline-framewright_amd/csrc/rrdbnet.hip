@@ -66,6 +66,7 @@ struct fw_rrdbnet {
     // conv_up1 / conv_up2 (nearest x2 + 3x3) as four 2x2 phase convolutions on the source grid: 4 instead of 9 taps per output pixel
     // (FW_RRDB_UP_PHASE=0 keeps the gathering nine-tap form, for A/B runs)
     bool up_phase = true;
+    int abl_rdb3 = 0;   // TIMING-ONLY ablation of rdb3's conv5 (wrong pixels): 1 no lo write, 2 no R lo planes, 4 no R hi planes (FW_RRDB_ABL_RDB3)
     // hipGraph capture of the per-frame forward (BASELINE configs[4] "hipGraph-captured per-frame stages").  graph_mode: 0 never
     // (default), 1 always, 2 for frames of at most graph_max_px input pixels.  Off by default because it buys nothing here: the
     // launches of a forward run back to back at 1080p, and even a 48x64 frame through 3 blocks takes 0.61 ms either way (the
@@ -348,6 +349,16 @@ void forward(fw_rrdbnet* n, const void* d_in, int bits, int H, int W, void* d_ou
                         p.chunk_off[2] = r_off + 6 * PB;     // R lo
                         p.chunk_off[3] = r_off + 7 * PB;
                         for (int i = 0; i < 4; ++i) p.id_scale[i] = 25.f;
+                        if (n->abl_rdb3 & 1) {
+                            p.out_lo = nullptr;
+                        }
+                        if (n->abl_rdb3 & 2) p.n_id = 2;
+                        if ((n->abl_rdb3 & 6) == 6) p.n_id = 0;
+                        else if (n->abl_rdb3 & 4) {
+                            p.n_id = 2;
+                            p.chunk_off[0] = p.chunk_off[2];
+                            p.chunk_off[1] = p.chunk_off[3];
+                        }
                     }
                 } else {
                     p.out_lo = plane(cat[nxt], 6, PL);
@@ -502,6 +513,7 @@ int fw_rrdbnet_create(int device_id, int num_block, int scale, int dtype, fw_rrd
         if (const char* e = getenv("FW_RRDB_LO")) n->rrdb_lo = atoi(e) != 0;
         if (const char* e = getenv("FW_RRDB_ABL_ALIAS")) n->abl_alias = atoi(e);
         if (const char* e = getenv("FW_RRDB_UP_PHASE")) n->up_phase = atoi(e) != 0;
+        if (const char* e = getenv("FW_RRDB_ABL_RDB3")) n->abl_rdb3 = atoi(e);
         *out = n.release();
     });
 }
