@@ -3,12 +3,13 @@
 # cite: the four bench lines, the NEWEST kernel-stats file of each path (gpurun_out/ accumulates over calls), the PMC summary and
 # the traffic file.  Run from the repo root after `gpurun -- bash profiles/refresh.sh`.
 set -e
-o=gpurun_out/r02
-for c in sr rife tap chain; do cp $o/bench_$c.json profiles/r02_bench_$c.json; done
+R=${FW_ROUND:-r03}
+o=gpurun_out/$R
+for c in sr rife tap chain; do cp $o/bench_$c.json profiles/${R}_bench_$c.json; done
 for c in sr tap rife restormer; do
     f=$(find $o/stats_$c -name "*_kernel_stats.csv" -printf "%T@ %p\n" | sort -n | tail -1 | cut -d" " -f2)
-    cp "$f" profiles/r02_${c}_kernel_stats.csv
+    cp "$f" profiles/${R}_${c}_kernel_stats.csv
 done
-cp $o/pmc_summary.json profiles/r02_pmc_summary.json
-cp $o/r02_traffic.json profiles/r02_traffic.json
-cp $o/r02_traffic_tap.json $o/r02_traffic_restormer.json profiles/
+cp $o/pmc_summary.json profiles/${R}_pmc_summary.json
+cp $o/${R}_traffic.json profiles/${R}_traffic.json
+cp $o/${R}_traffic_tap.json $o/${R}_traffic_restormer.json profiles/

@@ -1,20 +1,21 @@
 #!/bin/bash
 # Regenerates the judged profile artefacts of round 2 on the GPU box (run from the repo root through gpurun; ~6 min):
 #   gpurun_out/r02/pmc/p1,p2   FETCH_SIZE / WRITE_SIZE passes of the headline bench (separate passes), p3: MFMA-busy / LDS counters
-#   profiles/r02_traffic.json  per-launch and per-frame HBM traffic from p1 + p2, tagged with the build's digest (framewright_amd.build.source_digest(): sources + flags; written first,
+#   profiles/${R}_traffic.json  per-launch and per-frame HBM traffic from p1 + p2, tagged with the build's digest (framewright_amd.build.source_digest(): sources + flags; written first,
 #                              so that the bench line that follows quotes the traffic of THIS build)
 #   gpurun_out/r02/bench_{sr,rife,tap,chain}.json   the four bench lines
 #   gpurun_out/r02/stats_{sr,tap,rife,restormer}/   rocprofv3 --kernel-trace --stats summaries
 set -e
 root=$GRAFT_REPO_ROOT
-o="$root/gpurun_out/r02"
+R=${FW_ROUND:-r03}
+o="$root/gpurun_out/$R"
 mkdir -p "$o"
 bash "$root/profiles/pmc_pass.sh" "$o/pmc/p1" FETCH_SIZE
 bash "$root/profiles/pmc_pass.sh" "$o/pmc/p2" WRITE_SIZE
 bash "$root/profiles/pmc_pass.sh" "$o/pmc/p3" SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY
 cd "$root"
-python3 tools/make_traffic.py "$o/pmc" profiles/r02_traffic.json f16 > /dev/null
-cp profiles/r02_traffic.json "$o/r02_traffic.json"
+python3 tools/make_traffic.py "$o/pmc" profiles/${R}_traffic.json f16 > /dev/null
+cp profiles/${R}_traffic.json "$o/${R}_traffic.json"
 python3 profiles/pmc_summarize.py "$o/pmc" "$o/pmc_summary.json" || true
 # HBM traffic of one NAFNet 1080p forward and of one Restormer 512x512 tile (all kernels), for the `tap` bench line and DESIGN section 6
 bash "$root/profiles/pmc_pass_path.sh" "$o/pmc_tap/p1" tools/profile_nafnet.py FETCH_SIZE
@@ -22,9 +23,9 @@ bash "$root/profiles/pmc_pass_path.sh" "$o/pmc_tap/p2" tools/profile_nafnet.py W
 bash "$root/profiles/pmc_pass_path.sh" "$o/pmc_restormer/p1" tools/profile_restormer.py FETCH_SIZE
 bash "$root/profiles/pmc_pass_path.sh" "$o/pmc_restormer/p2" tools/profile_restormer.py WRITE_SIZE
 cd "$root"
-python3 tools/make_traffic_path.py "$o/pmc_tap" profiles/r02_traffic_tap.json 4 f16 > /dev/null
-python3 tools/make_traffic_path.py "$o/pmc_restormer" profiles/r02_traffic_restormer.json 3 f16 > /dev/null
-cp profiles/r02_traffic_tap.json profiles/r02_traffic_restormer.json "$o/"
+python3 tools/make_traffic_path.py "$o/pmc_tap" profiles/${R}_traffic_tap.json 4 f16 > /dev/null
+python3 tools/make_traffic_path.py "$o/pmc_restormer" profiles/${R}_traffic_restormer.json 3 f16 > /dev/null
+cp profiles/${R}_traffic_tap.json profiles/${R}_traffic_restormer.json "$o/"
 python3 bench.py > "$o/bench_sr.json" 2> "$o/bench_sr.err"
 python3 bench.py --config rife > "$o/bench_rife.json" 2> "$o/bench_rife.err"
 python3 bench.py --config tap > "$o/bench_tap.json" 2> "$o/bench_tap.err"
