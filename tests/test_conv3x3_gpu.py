@@ -244,14 +244,16 @@ def test_conv_chunk_planar_layout(hip_lib, dtype):
 
 
 @pytest.mark.parametrize("dtype", [_lib.FW_DTYPE_BF16, _lib.FW_DTYPE_F16])
-@pytest.mark.parametrize("slide", ["1", "0"])
+@pytest.mark.parametrize("slide", ["2", "1", "0"])
 @pytest.mark.parametrize("na,H,W", [(2, 14, 30), (2, 33, 71), (4, 40, 64), (2, 3, 5), (4, 29, 91), (2, 520, 330), (4, 1000, 200),
-                                    (2, 17, 1), (4, 16, 31)])
+                                    (2, 17, 1), (4, 16, 31), (2, 47, 32), (4, 130, 97)])
 def test_conv_pair_fused(hip_lib, dtype, na, H, W, slide, monkeypatch):
     """conv_a + conv_b fused vs two torch convs with x_a rounded to the operand type in between, chunk-planar layout, tile
     borders and image borders (zero padding of x_a).  Both forms of the kernel: the sliding window (conv3x3_pair_slide.hip:
     16-row steps, carried x_a rows, warm-up tiles where a workgroup starts mid-column - the two tall shapes give every
-    workgroup several tiles and column wraps) and the ring kernel (conv3x3_pair.hip: 14x30 valid outputs per tile)."""
+    workgroup several tiles and column wraps), the window kernel with all 32 columns of a tile valid (conv3x3_pair_slide32.hip,
+    "2": the two extra x_a columns come from column-shaped MFMAs) and the ring kernel (conv3x3_pair.hip: 14x30 valid outputs per
+    tile)."""
     monkeypatch.setenv("FW_PAIR_SLIDE", slide)
     rng = np.random.default_rng(na * 100 + H)
     cin = 32 * na
@@ -274,3 +276,30 @@ def test_conv_pair_fused(hip_lib, dtype, na, H, W, slide, monkeypatch):
     tol = 2e-2 if dtype == _lib.FW_DTYPE_BF16 else 3e-3
     assert (oa.float() - ref_a).abs().max().item() < tol
     assert (ob.float() - ref_b).abs().max().item() < 2 * tol
+
+
+@pytest.mark.parametrize("na,H,W", [(2, 530, 331), (4, 1000, 200), (2, 65, 2000)])
+def test_conv_pair_three_kernels_bit_identical(hip_lib, na, H, W, monkeypatch):
+    """The ring kernel, the 30-column window kernel and the 32-column window kernel accumulate every output pixel in the same order
+    (chunks in order, taps dx-major, fp32): identical bytes, f16 (the benched type)."""
+    dtype = _lib.FW_DTYPE_F16
+    rng = np.random.default_rng(7 * na + H)
+    cin = 32 * na
+    x = torch.from_numpy(rng.standard_normal((na, H, W, 32)).astype(np.float32)).cuda().to(TDT[dtype])
+    wa = (rng.standard_normal((32, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32)
+    wb = (rng.standard_normal((32, cin + 32, 3, 3)) / np.sqrt(9 * (cin + 32))).astype(np.float32)
+    ba, bb = rng.standard_normal(32).astype(np.float32), rng.standard_normal(32).astype(np.float32)
+    pa, pb = _pack(hip_lib, dtype, wa, 1, na), _pack(hip_lib, dtype, wb, 1, na + 1)
+    ta, tb = torch.from_numpy(ba).cuda(), torch.from_numpy(bb).cuda()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    outs = {}
+    for slide in ("0", "1", "2"):
+        monkeypatch.setenv("FW_PAIR_SLIDE", slide)
+        oa = torch.full((H, W, 32), 5.0, dtype=TDT[dtype], device="cuda")
+        ob = torch.full((H, W, 32), 5.0, dtype=TDT[dtype], device="cuda")
+        _lib.check(hip_lib.fw_conv3x3_pair_nhwc(dtype, p(x), 32, H * W * 32, na, H, W, p(pa), p(ta), p(pb), p(tb), p(oa), p(ob), 32, None))
+        torch.cuda.synchronize()
+        outs[slide] = (oa, ob)
+    for slide in ("1", "2"):
+        assert torch.equal(outs[slide][0], outs["0"][0]), f"x_a differs: kernel {slide} vs ring"
+        assert torch.equal(outs[slide][1], outs["0"][1]), f"x_b differs: kernel {slide} vs ring"

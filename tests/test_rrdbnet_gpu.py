@@ -418,21 +418,22 @@ def test_hipgraph_capture_gives_identical_frames(hip_lib, monkeypatch):
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 def test_sliding_window_pair_kernel_equals_ring_kernel_at_1080p(hip_lib, monkeypatch, dtype):
-    """Two independent implementations of the fused conv pair (conv3x3_pair_slide.hip, conv3x3_pair.hip) through the whole
-    23-block x4 network on a BASELINE-size frame: every byte of the 7680x4320 output must agree (same per-pixel
-    accumulation order)."""
+    """Three independent implementations of the fused conv pair (conv3x3_pair_slide32.hip, conv3x3_pair_slide.hip - the
+    default at this size -, conv3x3_pair.hip) through the whole 23-block x4 network on a BASELINE-size frame: every byte of the
+    7680x4320 output must agree (same per-pixel accumulation order)."""
     sd = synthetic_rrdbnet_state(23, 4, seed=1234)
     eng = R.RRDBNetEngine(23, 4, dtype)      # f16: exactly the network, size and operand type bench.py times
     eng.load_state_dict(sd)
     d = torch.from_numpy(synthetic_frames(1, 1080, 1920, seed=2)[0]).cuda()
     outs = []
-    for mode in ("1", "0"):
+    for mode in ("2", "1", "0"):
         monkeypatch.setenv("FW_PAIR_SLIDE", mode)
         o = torch.empty((4320, 7680, 3), dtype=torch.uint8, device="cuda")
         eng.upscale_device(d, out=o)
         torch.cuda.synchronize()
         outs.append(o)
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[1], outs[2])
     assert int(outs[0].max()) > int(outs[0].min())          # not a constant image
     eng.close()
 

@@ -344,6 +344,8 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_kern
 
 bool pair_slide_enabled(int H, int W, int num_cus);
 void launch_conv3x3_pair_slide(DType dt, const ConvPairParams& p, int num_cus, hipStream_t stream);
+bool pair_slide32_enabled();   // conv3x3_pair_slide32.hip: the window kernel with all 32 columns of a tile valid
+void launch_conv3x3_pair_slide32(DType dt, const ConvPairParams& p, int num_cus, hipStream_t stream);
 
 static int pair_num_cus() {
     static int n = [] {
@@ -374,7 +376,10 @@ void launch_conv3x3_pair(DType dt, const ConvPairParams& p_in, hipStream_t strea
     p.stamps = stamp_buffer(0);
 #endif
     if (pair_slide_enabled(p.H, p.W, pair_num_cus())) {  // the sliding-window form (conv3x3_pair_slide.hip) for all but small frames
-        launch_conv3x3_pair_slide(dt, p, pair_num_cus(), stream);
+        if (pair_slide32_enabled())
+            launch_conv3x3_pair_slide32(dt, p, pair_num_cus(), stream);
+        else
+            launch_conv3x3_pair_slide(dt, p, pair_num_cus(), stream);
         return;
     }
     const int tiles = ((p.W + PAIR_TW - 1) / PAIR_TW) * ((p.H + PAIR_TH - 1) / PAIR_TH);

@@ -224,6 +224,28 @@ __device__ __forceinline__ void glds16_batch_a(const void* sbase, const unsigned
         : "memory");
 }
 
+// Six pieces with their own per-lane offsets: the fifth piece is M0's, the sixth sits one KiB above it; voff[i] already contains
+// -(i - 4) KiB (conv3x3_pair_slide32.hip: 43 KiB per stage over eight waves = five waves of 5 and three of 6).
+__device__ __forceinline__ void glds16_batch_a6(const void* sbase, const unsigned* voff, unsigned lds_piece4) {
+    const unsigned long long b = (unsigned long long)sbase;
+    const unsigned long long sb = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) << 32) |
+                                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)b);
+    lds_piece4 = __builtin_amdgcn_readfirstlane(lds_piece4);
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 m0, %7\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %6 offset:-4096\n\t"
+        "global_load_lds_dwordx4 %1, %6 offset:-3072\n\t"
+        "global_load_lds_dwordx4 %2, %6 offset:-2048\n\t"
+        "global_load_lds_dwordx4 %3, %6 offset:-1024\n\t"
+        "global_load_lds_dwordx4 %4, %6\n\t"
+        "global_load_lds_dwordx4 %5, %6 offset:1024"
+        :
+        : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]), "v"(voff[5]), "s"(sb), "s"(lds_piece4)
+        : "memory");
+}
+
 // Four pieces with their own per-lane offsets (the GEMM kernel's activation rows); voff[i] already contains -(i - 3) KiB and
 // lds_piece3 is the LDS address of the FOURTH piece.
 __device__ __forceinline__ void glds16_batch_a4(const void* sbase, const unsigned* voff, unsigned lds_piece3) {
@@ -334,9 +356,10 @@ unsigned long long* stamp_buffer(int which);
 // before its first use.
 // dma_slot(k), k = 0..35, is called after every 2*(NW - W_LO) MFMAs; on_centre(xc) once with the centre-tap B fragments
 // xc[row][ph] (the wave's own pixels).
-template <typename T, int NW, int W_LO, typename WIdx, typename Slot, typename Centre, typename Hook>
-__device__ __forceinline__ void conv_item(f32x4 (&acc)[RPW][NW][2], const uint4* a, const uint4* wl, const int (&rd_off)[3][2],
-                                          WIdx widx, Slot dma_slot, Centre on_centre, Hook step_hook) {
+// conv_item_rp: the same with ROWP pieces per halo row of the stage (the 36-pixel stages of conv3x3_pair_slide32.hip: 145).
+template <int ROWP, typename T, int NW, int W_LO, typename WIdx, typename Slot, typename Centre, typename Hook>
+__device__ __forceinline__ void conv_item_rp(f32x4 (&acc)[RPW][NW][2], const uint4* a, const uint4* wl, const int (&rd_off)[3][2],
+                                             WIdx widx, Slot dma_slot, Centre on_centre, Hook step_hook) {
     constexpr int NWU = NW - W_LO;
     constexpr int NK = 9 * NWU;  // weight fragments of the item, in use order
     uint4 xr[RPW + 2][2];
@@ -353,7 +376,7 @@ __device__ __forceinline__ void conv_item(f32x4 (&acc)[RPW][NW][2], const uint4*
 #pragma unroll
     for (int row = 0; row < RPW + 2; ++row)
 #pragma unroll
-        for (int ph = 0; ph < 2; ++ph) xr[row][ph] = a[row * ROW_PIECES + rd_off[0][ph]];
+        for (int ph = 0; ph < 2; ++ph) xr[row][ph] = a[row * ROWP + rd_off[0][ph]];
 #pragma unroll
     for (int k = 0; k < RING - 1; ++k) load_w(k);
     FW_SB();
@@ -362,13 +385,13 @@ __device__ __forceinline__ void conv_item(f32x4 (&acc)[RPW][NW][2], const uint4*
         const int dx = t / 3, dy = t - 3 * dx;
         if (dx < 2 && dy >= 1) {
 #pragma unroll
-            for (int ph = 0; ph < 2; ++ph) xr[dy - 1][ph] = a[(dy - 1) * ROW_PIECES + rd_off[dx + 1][ph]];
+            for (int ph = 0; ph < 2; ++ph) xr[dy - 1][ph] = a[(dy - 1) * ROWP + rd_off[dx + 1][ph]];
         }
         if (dx > 0 && dy == 0) {
 #pragma unroll
             for (int row = 2; row < RPW + 2; ++row)
 #pragma unroll
-                for (int ph = 0; ph < 2; ++ph) xr[row][ph] = a[row * ROW_PIECES + rd_off[dx][ph]];
+                for (int ph = 0; ph < 2; ++ph) xr[row][ph] = a[row * ROWP + rd_off[dx][ph]];
         }
 #pragma unroll
         for (int w = 0; w < NWU; ++w) {
@@ -397,6 +420,12 @@ __device__ __forceinline__ void conv_item(f32x4 (&acc)[RPW][NW][2], const uint4*
         }
         step_hook(t);  // diagnostics only (phase stamps)
     }
+}
+
+template <typename T, int NW, int W_LO, typename WIdx, typename Slot, typename Centre, typename Hook>
+__device__ __forceinline__ void conv_item(f32x4 (&acc)[RPW][NW][2], const uint4* a, const uint4* wl, const int (&rd_off)[3][2],
+                                          WIdx widx, Slot dma_slot, Centre on_centre, Hook step_hook) {
+    conv_item_rp<ROW_PIECES, T, NW, W_LO>(acc, a, wl, rd_off, widx, dma_slot, on_centre, step_hook);
 }
 
 }  // namespace fw
