@@ -298,14 +298,14 @@ def main():
             sr.profile_enable(False)
             achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
             traffic, note = None, None
-            tf = ROOT / "profiles" / "r02_traffic.json"
-            if tf.exists() and (H, W, args.model) == (1080, 1920, "RealESRGAN_x4plus"):
+            tf = newest_profile("traffic.json")
+            if tf is not None and (H, W, args.model) == (1080, 1920, "RealESRGAN_x4plus"):
                 tj = json.loads(tf.read_text())
                 if tj.get("lib_digest") == lib_digest() and tj.get("dtype") == args.dtype:
                     traffic = tj["hbm_bytes_per_launch"]
-                    note = f"profiles/r02_traffic.json, measured on this build ({tj['lib_digest']}): {tj['hbm_gb_per_frame']:.0f} GB per frame"
+                    note = f"profiles/{tf.name}, measured on this build ({tj['lib_digest']}): {tj['hbm_gb_per_frame']:.0f} GB per frame"
                 else:
-                    note = "profiles/r02_traffic.json was measured on another build or dtype: not quoted"
+                    note = f"profiles/{tf.name} was measured on another build or dtype: not quoted"
             roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
                     "traffic": traffic, "traffic_source": note,
                     "kernel": "conv3x3_pair_slide_kernel + conv3x3_mfma_kernel (every conv launch of the Real-ESRGAN forward)",
@@ -329,14 +329,14 @@ def main():
             nbytes = nafnet_design_bytes(H, W) if cfg == "tap" else ifnet_design_bytes(H, W)
             gbs = nbytes / (ms * 1e-3) / 1e9
             traffic, note = None, None
-            tf = ROOT / "profiles" / "r02_traffic_tap.json"
-            if cfg == "tap" and tf.exists() and (H, W) == (1080, 1920):
+            tf = newest_profile("traffic_tap.json")
+            if cfg == "tap" and tf is not None and (H, W) == (1080, 1920):
                 tj = json.loads(tf.read_text())
                 if tj.get("lib_digest") == lib_digest() and tj.get("dtype") == args.dtype:
                     traffic = tj["hbm_bytes_per_forward"]
-                    note = f"profiles/r02_traffic_tap.json, PMC counters of this build ({tj['lib_digest']}): {traffic / 1e9:.1f} GB per forward"
+                    note = f"profiles/{tf.name}, PMC counters of this build ({tj['lib_digest']}): {traffic / 1e9:.1f} GB per forward"
                 else:
-                    note = "profiles/r02_traffic_tap.json was measured on another build or dtype: not quoted"
+                    note = f"profiles/{tf.name} was measured on another build or dtype: not quoted"
             roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": traffic,
                     "traffic_source": note,
                     "kernel": "one NAFNet-width64 forward (all kernels)" if cfg == "tap" else "one IFNet v4.6 forward (all kernels)",
@@ -418,6 +418,13 @@ def main():
     if world > 1:
         barrier()
         dist.destroy_process_group()
+
+
+def newest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that has one (the measured-traffic files carry the digest of the build they were taken
+    on: a line only quotes the file when the digests agree)."""
+    found = sorted((ROOT / "profiles").glob(f"r[0-9][0-9]_{suffix}"))
+    return found[-1] if found else None
 
 
 def parity_and_cpu(cfg, args, clip, sr, ifn, naf, sd_sr, sd_if, sd_naf, num_block, scale, frame_px):

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Regenerates the judged profile artefacts of round 2 on the GPU box (run from the repo root through gpurun; ~6 min):
-#   gpurun_out/r02/pmc/p1,p2   FETCH_SIZE / WRITE_SIZE passes of the headline bench (separate passes), p3: MFMA-busy / LDS counters
+# Regenerates the judged profile artefacts of a round (FW_ROUND, default r03) on the GPU box (run from the repo root through gpurun; ~9 min):
+#   gpurun_out/$R/pmc/p1,p2   FETCH_SIZE / WRITE_SIZE passes of the headline bench (separate passes), p3: MFMA-busy / LDS counters
 #   profiles/${R}_traffic.json  per-launch and per-frame HBM traffic from p1 + p2, tagged with the build's digest (framewright_amd.build.source_digest(): sources + flags; written first,
 #                              so that the bench line that follows quotes the traffic of THIS build)
-#   gpurun_out/r02/bench_{sr,rife,tap,chain}.json   the four bench lines
-#   gpurun_out/r02/stats_{sr,tap,rife,restormer}/   rocprofv3 --kernel-trace --stats summaries
+#   gpurun_out/$R/bench_{sr,rife,tap,chain}.json   the four bench lines
+#   gpurun_out/$R/stats_{sr,tap,rife,restormer}/   rocprofv3 --kernel-trace --stats summaries
 set -e
 root=$GRAFT_REPO_ROOT
 R=${FW_ROUND:-r03}
@@ -32,6 +32,12 @@ python3 bench.py --config tap > "$o/bench_tap.json" 2> "$o/bench_tap.err"
 python3 bench.py --config chain > "$o/bench_chain.json" 2> "$o/bench_chain.err"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$o/stats_sr" -- python3 "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-host-path > "$o/stats_sr.log" 2>&1
+cd "$root"
+# socket power under the headline bench (same box as the kernel trace above) -> joules per frame and per launch class; the other paths' timings
+bash tools/power_trace.sh "$o/power_trace.log"
+python3 tools/energy_table.py "$o/power_trace.log" "$o/power_trace_bench.json" "$(find $o/stats_sr -name "*_kernel_trace.csv" -printf "%T@ %p\n" | sort -n | tail -1 | cut -d" " -f2)" "$o/power_trace.json" "$o/energy.json" > "$o/energy_table.md"
+python3 tools/time_paths.py > "$o/secondary_paths.json" 2> "$o/secondary_paths.err" || true
+cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$o/stats_tap" -- python3 "$root/tools/profile_nafnet.py" > "$o/stats_tap.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$o/stats_rife" -- python3 "$root/tools/profile_ifnet.py" > "$o/stats_rife.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$o/stats_restormer" -- python3 "$root/tools/profile_restormer.py" > "$o/stats_restormer.log" 2>&1

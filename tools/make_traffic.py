@@ -5,7 +5,7 @@
 
 Per MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE are collected in separate passes, are in
 KiB, and on gfx950 FETCH_SIZE tallies 128-byte requests at 64 B, so it is doubled.  The figures are the average over every
-conv launch (conv3x3_mfma_kernel and conv3x3_pair*_kernel) of `bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-path`
+conv launch (conv3x3_mfma_kernel, conv3x3_pair*_kernel, conv_up2x_phase_kernel) of `bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-path`
 and the sum over the 213 conv launches of one frame.  The file is tagged with the digest of the library it was measured on:
 bench.py quotes it only when that is the library it runs.
 """
@@ -19,7 +19,7 @@ per_kernel = {}
 launches, dur_ns = {}, {}
 for f in glob.glob(f"{src}/p*/**/*_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "conv3x3" not in r["Kernel_Name"] or r["Counter_Name"] not in tot:
+        if not ("conv3x3" in r["Kernel_Name"] or "conv_up2x_phase" in r["Kernel_Name"]) or r["Counter_Name"] not in tot:
             continue
         v = float(r["Counter_Value"])
         tot[r["Counter_Name"]] += v
@@ -39,7 +39,7 @@ root = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(root))
 from framewright_amd import build as _build   # the digest names the build by its sources and flags
 json.dump({
-    "kernel": "conv3x3_mfma_kernel + conv3x3_pair_slide_kernel (all instantiations)",
+    "kernel": "conv3x3_mfma_kernel + conv3x3_pair_slide_kernel + conv_up2x_phase_kernel (all instantiations)",
     "lib_digest": _build.source_digest(),
     "dtype": dtype,
     "launches": n,
