@@ -195,11 +195,13 @@ def test_restormer_vs_oracle(hip_lib, dtype, max_abs, min_psnr):
     eng.close()
 
 
+@pytest.mark.parametrize("dw_mfma", ["0", "1"])
 @pytest.mark.parametrize("H,W", [(40, 56), (136, 200)])
-def test_fused_fronts_equal_the_staged_kernels(hip_lib, monkeypatch, H, W):
+def test_fused_fronts_equal_the_staged_kernels(hip_lib, monkeypatch, H, W, dw_mfma):
     """LayerNorm + 1x1 + depthwise 3x3 (+ GDFN gate) of the 48- / 96-channel blocks as one kernel (pw_dw_fused.hip) against the
     three kernels it replaces (FW_REST_FUSE_FRONT=0).  Not bit-equal: the LayerNorm's affine part is folded into the 1x1 weights and
     the GELU's erf is a 1.5e-7 polynomial.  136 x 200 has ragged tiles in both directions and several tiles per workgroup row."""
+    monkeypatch.setenv("FW_PW_DW_MFMA", dw_mfma)   # "1": the fused kernel with its depthwise phase on the matrix cores (pw_dw_mfma_kernel, opt-in)
     sd = RS.synthetic_restormer_state(seed=5, **SMALL)
     t = torch.from_numpy(synthetic_frames(1, H, W, seed=13)[0]).cuda()
     outs = []

@@ -260,13 +260,14 @@ def test_clip_driver_with_preserve_grain(hip_lib, tmp_path, monkeypatch):
     m.clear_cache()
 
 
-@pytest.mark.parametrize("H,W", [(272, 400), (1080, 1920)])
-def test_deep_level_gemm_kernel_equals_the_staged_kernel(hip_lib, monkeypatch, H, W):
+@pytest.mark.parametrize("H,W,dw_mfma", [(272, 400, "0"), (272, 400, "1"), (1080, 1920, "0")])
+def test_deep_level_gemm_kernel_equals_the_staged_kernel(hip_lib, monkeypatch, H, W, dw_mfma):
     """The pipelined GEMM kernel of the >= 256-channel levels (pointwise_gemm.hip: 256 x 256 tiles, LDS-DMA, SimpleGate / residual
     epilogues, SCA folded into scaled weights) against the register-staged pointwise kernel it replaces there (FW_NAF_GEMM=0):
     the same fp32 accumulation of the same rounded operands up to summation order, except for conv3, whose SCA factor multiplies
     the weights instead of the activations (one more rounding of an operand).  At 272 x 400 the deep levels have 425 / 119 / 34
     pixels (ragged pixel tiles, rows clamped); 1080p is the BASELINE size (several tiles per workgroup)."""
+    monkeypatch.setenv("FW_PW_DW_MFMA", dw_mfma)   # "1": the fused front with its depthwise phase on the matrix cores (SimpleGate + SCA sums)
     sd = synthetic_nafnet_state(seed=11, **FULL)
     frame = synthetic_frames(1, H, W, seed=3)[0]
     t = torch.from_numpy(frame).cuda()

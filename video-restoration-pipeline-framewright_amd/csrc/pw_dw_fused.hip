@@ -23,6 +23,8 @@
 //   * the result overwrites the wave's own slots of the LDS image and leaves in 16-byte pieces, 64 (gate) or 128 contiguous
 //     bytes per pixel; the SimpleGate sums stay in registers for the SCA pooling (wave reduction at the end of the kernel ->
 //     partial[workgroup][c], the fixed-order scheme of dwconv3x3_gate_kernel).
+#include <cstdlib>
+#include <type_traits>
 #include "fw_internal.h"
 #include "conv_common.h"
 
@@ -33,7 +35,9 @@ constexpr int FR_OR = 14, FR_OC = 30;                 // output tile
 constexpr int FR_PXB = 136;                           // LDS bytes per pixel record: 64 channels + 8 pad
 constexpr int FR_Y_BYTES = FR_HR * FR_HC * FR_PXB;    // 69632
 constexpr int FR_STRIP = 7;                           // output rows per depthwise item
-constexpr int FR_TAIL = 11 * 64 * 4;                  // per chunk: depthwise taps [9][64], depthwise bias [64], conv bias [64] (fp32)
+constexpr int FR_TAIL32 = 11 * 64 * 4;                // per chunk: depthwise taps [9][64], depthwise bias [64], conv bias [64] (fp32)
+constexpr int FR_TAPS16 = 64 * 3 * 2 * 4;             // ... and the taps once more for the matrix-core depthwise phase: [64][3 tap rows] x {w1 << 16 | w0, w2}, f16 bits
+constexpr int FR_TAIL = FR_TAIL32 + FR_TAPS16;
 
 constexpr int pw_dw_block_bytes(int kc) { return (kc * 4096 + FR_TAIL + 1023) / 1024 * 1024; }
 
@@ -359,6 +363,362 @@ __global__ __launch_bounds__(512, 2) void pw_dw_kernel(const PwDwParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same kernel with the depthwise 3x3 on the MATRIX CORES: opt-in (FW_PW_DW_MFMA=1), correct and tested, NOT faster - measured below.
+// In pw_dw_kernel the depthwise phase is VALU-issue-bound - a conversion per loaded value, half a packed FMA per MAC, ~1000 issue
+// slots per 64-channel chunk and wave - and takes 55 % of the GDFN kernel (tools/front_stamps.py).  Per channel c and tap row dy,
+//     D[m][n] += sum_k A_dy[m][k] * B[k][n],   m = output column (16), k = input column (32), n = image row (16)
+//     A_dy[m][k] = w[c][dy][k - m] for 0 <= k - m <= 2, else 0     (a Toeplitz band built in registers with four v_perm_b32 from the
+//                  taps - the byte selectors are per-lane constants)
+//     B[k][n]    = y[c][n + dy][col0 + k]                          (one ds_read_b128 per lane from a CHANNEL-MAJOR LDS tile)
+// is 3 v_mfma_f32_16x16x32 per channel and 16 x 16 outputs: 9 % of their MACs are useful and it is still half the VALU phase's
+// cycles (tools/dw_mfma.py, profiles/r02_dw_mfma.json: 4.25k against 8.2k per 64 channels of a tile).  What the kernel needs for it:
+//   * the 1x1 conv with its operands SWAPPED (A = the pixels' B fragments of phase A, B = the weight fragments - both keep their
+//     k order): D holds four consecutive PIXELS of one channel per lane, i.e. 8-byte pieces of a channel-major row;
+//   * a chunk in two halves of 32 channels (gate modes: the x1 half, then the x2 half), each through a [32 ch][16 + 2 rows][56]
+//     f16 image (row stride 28 dwords: conflict-free b128 reads; the pad columns and rows are zeroed once and never written, so
+//     the band's zero entries never meet a NaN); wave w owns channels 4w .. 4w + 3 of the half, as before;
+//   * the gate on the D fragments (x1 of the first half stays in registers), the SCA sums likewise;
+//   * a pixel-major way out: the wave's four channels of a pixel are 8 bytes of a [420 px][64 or 128 B (+ 8)] image from which the
+//     workgroup stores 16-byte pieces as before.
+// Taps are rounded to the operand type (like the 1x1 weights), products are exact in fp32, the sum is fp32.
+// Measured (round 3, phase stamps of a Restormer 512 x 512 tile and A/B of whole forwards on one box, profiles/r03_ab/pw_dw_mfma.txt):
+// like for like - the qkv front, no gate - the depthwise phase goes from 5.3k to 3.7k cycles per 64-channel chunk (1.6k with the
+// output writes taken out); the 8.2k of the GDFN front that round 2's microbenchmark was set against also hold the erf GELU (2.8k)
+// and the gate + output writes (2.0k), which stay.  The two extra barriers per chunk (a half's image must be read out before the
+// next half overwrites it), the wait they add at the chunk's first barrier and the channel-major store give that back:
+// Restormer tile 10.03 against 9.91 ms, NAFNet 1080p forward 14.15 against 14.08 ms.  A chunk of this kernel is ~16k cycles in eight
+// phases of 0.6k - 2.8k each (phase A 1.6k, GEMM 2.0k, image store 1.9k, barriers 2.2k, depthwise 1.6k, GELU 2.8k, gate + output
+// image 2.0k, global stores 0.6k): no single phase is worth more than a sixth.
+constexpr int DM_RS = 56;                              // halves per image row
+constexpr int DM_ROWS = FR_HR + 2;                     // 16 rows + the two the last output rows' taps reach into
+constexpr int DM_PLANE = DM_ROWS * DM_RS * 2 + 16;     // bytes per channel: + 16 spreads the 16 channels of a GEMM store over the banks
+constexpr int DM_Y_BYTES = 32 * DM_PLANE;              // 65024
+
+template <typename T, int CG, int MODE>
+__global__ __launch_bounds__(512, 2) void pw_dw_mfma_kernel(const PwDwParams p) {
+    constexpr int KC = (CG + 1) / 2;
+    constexpr int PB = pw_dw_block_bytes(KC);
+    constexpr int NPIECE = PB / 1024;
+    constexpr bool GATE = MODE != PWDW_NONE;
+    constexpr int OUT_B = GATE ? 64 : 128;            // output bytes per pixel and chunk
+    constexpr int OSTR = OUT_B + 8;                   // bytes per pixel record of the output image
+    constexpr int O_BYTES = (FR_OR * FR_OC * OSTR + 15) / 16 * 16;
+    __shared__ __attribute__((aligned(16))) char ych[DM_Y_BYTES];
+    __shared__ __attribute__((aligned(16))) char obuf[O_BYTES];
+    __shared__ __attribute__((aligned(16))) char pbuf[2 * PB];
+    static_assert(DM_Y_BYTES + O_BYTES + 2 * PB <= 160 * 1024, "LDS");
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, q = lane & 15, sl = lane >> 4;
+    const unsigned pb_lds = (unsigned)(size_t)(lds_ptr_t)pbuf;
+    const char* blocks = reinterpret_cast<const char*>(p.blocks);
+    const int nch = p.n_chunks;
+
+    auto fetch = [&](int chunk, int buf) {
+        for (int i = wave; i < NPIECE; i += 8)
+            glds16(blocks + (size_t)chunk * PB + i * 1024, lane * 16, pb_lds + buf * PB + i * 1024);
+    };
+
+    const int tiles_x = (p.W + FR_OC - 1) / FR_OC, tiles_y = (p.H + FR_OR - 1) / FR_OR;
+    const long ntiles = (long)tiles_x * tiles_y;
+    const long t_lo = blockIdx.x * ntiles / gridDim.x, t_hi = (long)(blockIdx.x + 1) * ntiles / gridDim.x;
+    if (t_lo >= t_hi) return;
+    fetch(0, 0);
+    // zero the image once: pad columns 32..55 and pad rows 16, 17 are never written again
+    for (int i = tid; i < DM_Y_BYTES / 16; i += 512) reinterpret_cast<uint4*>(ych)[i] = make_uint4(0, 0, 0, 0);
+
+    // band selectors of this lane's A fragment (row m = q, k = 8 sl + 2 i + hh): tap d = k - m in {0, 1, 2} or none
+    unsigned sel[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned v = 0;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int d = 8 * sl + 2 * i + hh - q;
+            const unsigned pair = (d == 0) ? 0x0100u : (d == 1) ? 0x0302u : (d == 2) ? 0x0504u : 0x0706u;   // bytes of {S1 = (0, w2), S0 = (w1, w0)}
+            v |= pair << (16 * hh);
+        }
+        sel[i] = v;
+    }
+
+    f32x4 cs[4];                                      // PWDW_GATE_MUL: pooled sums of up to four chunks (c <= 128), this wave's four channels
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float inv_c = 1.0f / (float)(16 * CG);
+    unsigned g = 0;                                   // chunks done: parameter buffer = g & 1
+#ifdef FW_FRONT_STAMP   // diagnostic build: cycles per phase of one wave, printed at the end (FW_PH: defined with pw_dw_kernel above)
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = __builtin_amdgcn_s_memtime(), t_begin = tq;
+#endif
+
+    for (long tile = t_lo; tile < t_hi; ++tile) {
+        const int tyi = (int)(tile / tiles_x);
+        const int ty0 = tyi * FR_OR, tx0 = (int)(tile - (long)tyi * tiles_x) * FR_OC;
+
+        // ---- phase A: this wave's 64 halo pixels -> normalised fragments (pw_dw_kernel's, unchanged) ----------------------------
+        uint4 xb[4][KC];
+        constexpr int TB = CG > 4 ? 2 : 4;
+#pragma unroll
+        for (int t0 = 0; t0 < 4; t0 += TB) {
+            f32x4 v[TB][CG];
+#pragma unroll
+            for (int tt = 0; tt < TB; ++tt) {
+                const int t = t0 + tt;
+                const int gy = ty0 - 1 + 2 * wave + (t >> 1), gx = tx0 - 1 + 16 * (t & 1) + q;
+                const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
+                const float* src = p.x + ((long)cy * p.W + cx) * p.ldx + 4 * sl;
+#pragma unroll
+                for (int m = 0; m < CG; ++m) v[tt][m] = *reinterpret_cast<const f32x4*>(src + 16 * m);
+            }
+#pragma unroll
+            for (int tt = 0; tt < TB; ++tt) {
+                const int t = t0 + tt;
+                float s = 0.f;
+#pragma unroll
+                for (int m = 0; m < CG; ++m) s += (v[tt][m][0] + v[tt][m][1]) + (v[tt][m][2] + v[tt][m][3]);
+                s += __shfl_xor(s, 16);
+                s += __shfl_xor(s, 32);
+                const float mean = s * inv_c;
+                float ss = 0.f;
+#pragma unroll
+                for (int m = 0; m < CG; ++m) {
+                    v[tt][m] = v[tt][m] - mean;
+                    ss += (v[tt][m][0] * v[tt][m][0] + v[tt][m][1] * v[tt][m][1]) + (v[tt][m][2] * v[tt][m][2] + v[tt][m][3] * v[tt][m][3]);
+                }
+                ss += __shfl_xor(ss, 16);
+                ss += __shfl_xor(ss, 32);
+                const float rstd = 1.0f / __builtin_sqrtf(ss * inv_c + p.ln_eps);
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) {
+                    uint2 h[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (2 * kc + u < CG) {
+                            const f32x4 n = v[tt][2 * kc + u] * rstd;
+                            h[u] = Op<T>::pack4(n[0], n[1], n[2], n[3]);
+                        } else {
+                            h[u] = make_uint2(0u, 0u);
+                        }
+                    }
+                    xb[t][kc] = make_uint4(h[0].x, h[0].y, h[1].x, h[1].y);
+                }
+            }
+        }
+        FW_PH(0);
+        // which of the lane's GEMM outputs lie inside the image (the depthwise conv pads the 1x1 conv's OUTPUT with zeros):
+        // D fragment of pixel tile t = halo row 2 wave + (t >> 1), columns 16 (t & 1) + 4 sl + r
+        unsigned inside = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int gy = ty0 - 1 + 2 * wave + (t >> 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gx = tx0 - 1 + 16 * (t & 1) + 4 * sl + r;
+                inside |= (unsigned)(gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) << (4 * t + r);
+            }
+        }
+
+#pragma unroll 1
+        for (int j = 0; j < nch; ++j, ++g) {
+            const char* pb = pbuf + (g & 1) * PB;
+            const float* tail = reinterpret_cast<const float*>(pb + KC * 4096);            // [9][64] taps (unused here), [64] depthwise bias, [64] conv bias
+            const uint2* taps16 = reinterpret_cast<const uint2*>(pb + KC * 4096 + FR_TAIL32);   // [64][3]
+            FW_WAIT_VMCNT(0);
+            __syncthreads();     // the chunk's parameters have landed; the previous chunk's store phase is done with obuf, its depthwise phase with ych
+            {
+                const bool last = j + 1 == nch;
+                if (!(last && tile + 1 == t_hi)) fetch(last ? 0 : j + 1, (int)((g + 1) & 1));
+            }
+            FW_PH(2);
+            const uint4* wl = reinterpret_cast<const uint4*>(pb) + lane;
+            f32x4 x1[4][2];      // gate modes: the first half's depthwise outputs (GELU'd for the GDFN gate)
+            f32x4 cj = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+                // ---- 1x1 conv, channels 32 half .. + 31 of the chunk x this wave's 64 pixels, operands swapped: lane = (channel q of a
+                //      16-channel tile, pixels 4 sl .. 4 sl + 3 of a 16-pixel tile) -------------------------------------------------------
+                f32x4 acc[4][2];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) acc[t][c2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) {
+                        const uint4 wf = wl[(kc * 4 + 2 * half + c2) * 64];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc[t][c2] = Op<T>::mfma16(xb[t][kc], wf, acc[t][c2]);
+                    }
+                FW_PH(1);
+                if (half) __syncthreads();   // every wave is done reading the first half's image
+                FW_PH(4);
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    const float bs = tail[10 * 64 + 32 * half + 16 * c2 + q];
+                    char* yc = ych + (16 * c2 + q) * DM_PLANE + 8 * sl;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        f32x4 y = acc[t][c2] + bs;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (!((inside >> (4 * t + r)) & 1u)) y[r] = 0.f;
+                        *reinterpret_cast<uint2*>(yc + ((2 * wave + (t >> 1)) * DM_RS + 16 * (t & 1)) * 2) = Op<T>::pack4(y[0], y[1], y[2], y[3]);
+                    }
+                }
+                FW_PH(3);
+                __syncthreads();
+                FW_PH(4);
+
+                // ---- depthwise 3x3 of channels 4 wave .. + 3 of the half: 3 tap rows x 2 column halves MFMAs per channel -----------------
+                f32x4 d[4][2];
+                {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(tail + 9 * 64 + 32 * half + 4 * wave);
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) d[cc][0] = d[cc][1] = f32x4{bv[cc], bv[cc], bv[cc], bv[cc]};
+                }
+                uint2 tp[4][3];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) tp[cc][dy] = taps16[(32 * half + 4 * wave + cc) * 3 + dy];
+                const char* yr = ych + (4 * wave) * DM_PLANE + (q * DM_RS + 8 * sl) * 2;
+                // One ds_read_b128 per channel and column half: lane n holds row n, and the fragments of tap rows 1 and 2 are the same
+                // registers shifted by one / two lanes within the 16-lane row (v_mov_b32 row_shl: lane n takes lane n + dy; lanes past the
+                // row get zero - they belong to output rows 14, 15, which the 14-row tile does not have).  Reading row n + dy from LDS
+                // instead made the phase LDS-bound: 48 KiB-reads per wave and chunk, ~4.0k cycles per chunk against the VALU phase's 5.3k
+                // (without the gate; gpurun_out/r03/stamps_*.log).
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    uint4 A[3];
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const uint2 t2 = tp[cc][dy];
+                        A[dy] = make_uint4(__builtin_amdgcn_perm(t2.y, t2.x, sel[0]), __builtin_amdgcn_perm(t2.y, t2.x, sel[1]),
+                                           __builtin_amdgcn_perm(t2.y, t2.x, sel[2]), __builtin_amdgcn_perm(t2.y, t2.x, sel[3]));
+                    }
+#pragma unroll
+                    for (int xh = 0; xh < 2; ++xh) {
+                        const uint4 B0 = *reinterpret_cast<const uint4*>(yr + cc * DM_PLANE + (16 * xh) * 2);
+                        auto shl = [](unsigned v, auto dyc) {
+                            constexpr int DY = decltype(dyc)::value;
+                            return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + DY, 0xf, 0xf, true);
+                        };
+                        const uint4 B1 = make_uint4(shl(B0.x, std::integral_constant<int, 1>{}), shl(B0.y, std::integral_constant<int, 1>{}),
+                                                    shl(B0.z, std::integral_constant<int, 1>{}), shl(B0.w, std::integral_constant<int, 1>{}));
+                        const uint4 B2 = make_uint4(shl(B0.x, std::integral_constant<int, 2>{}), shl(B0.y, std::integral_constant<int, 2>{}),
+                                                    shl(B0.z, std::integral_constant<int, 2>{}), shl(B0.w, std::integral_constant<int, 2>{}));
+                        d[cc][xh] = Op<T>::mfma16(A[0], B0, d[cc][xh]);
+                        d[cc][xh] = Op<T>::mfma16(A[1], B1, d[cc][xh]);
+                        d[cc][xh] = Op<T>::mfma16(A[2], B2, d[cc][xh]);
+                    }
+                }
+                // d[cc][xh][r] = output (row q, column 16 xh + 4 sl + r) of channel 4 wave + cc of the half
+                if (GATE && half == 0) {
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                        for (int xh = 0; xh < 2; ++xh) {
+                            if constexpr (MODE == PWDW_GATE_GELU) {
+                                const f32x2 a = gelu_erf2(f32x2{d[cc][xh][0], d[cc][xh][1]}), b = gelu_erf2(f32x2{d[cc][xh][2], d[cc][xh][3]});
+                                x1[cc][xh] = f32x4{a[0], a[1], b[0], b[1]};
+                            } else {
+                                x1[cc][xh] = d[cc][xh];
+                            }
+                        }
+                } else {
+#pragma unroll
+                    for (int xh = 0; xh < 2; ++xh)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int ocol = 16 * xh + 4 * sl + r;
+                            f32x4 o;
+#pragma unroll
+                            for (int cc = 0; cc < 4; ++cc) o[cc] = GATE ? x1[cc][xh][r] * d[cc][xh][r] : d[cc][xh][r];
+                            if (q < FR_OR && ocol < FR_OC) {
+                                *reinterpret_cast<uint2*>(obuf + (q * FR_OC + ocol) * OSTR + (GATE ? 0 : 64 * half) + 8 * wave) = Op<T>::pack4(o[0], o[1], o[2], o[3]);
+                                if (MODE == PWDW_GATE_MUL && ty0 + q < p.H && tx0 + ocol < p.W) cj += o;
+                            }
+                        }
+                }
+            }
+            FW_PH(5);
+            __syncthreads();
+            FW_PH(6);
+            // ---- the chunk leaves in 16-byte pieces ---------------------------------------------------------------------------------------
+            bool transposed = false;
+            if constexpr (MODE == PWDW_NONE) transposed = p.qT && j < p.t_chunks;
+            if (transposed) {
+                // q / k for the Gram kernel: 16 bytes = 8 pixels of one channel, pixels in tile order, zeros where the tile has none
+                T* dst = reinterpret_cast<T*>(p.qT) + 64 * 8 * j;
+                constexpr int GROUPS = (FR_OR * FR_OC + 7) / 8 + 3;   // 56: 448 pixels, a multiple of 32
+                const char* och = obuf + 2 * lane;
+#pragma unroll 1
+                for (int gq = wave; gq < GROUPS; gq += 8) {
+                    unsigned w4[4];
+                    int orow = (gq * 8) / FR_OC, ocol = gq * 8 - orow * FR_OC;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const bool ok = gq * 8 + e < FR_OR * FR_OC && ty0 + orow < p.H && tx0 + ocol < p.W;     // wave-uniform
+                        unsigned u = 0;
+                        if (ok) u = *reinterpret_cast<const unsigned short*>(och + (orow * FR_OC + ocol) * OSTR);
+                        if (e & 1) w4[e >> 1] |= u << 16; else w4[e >> 1] = u;
+                        if (++ocol == FR_OC) {
+                            ocol = 0;
+                            ++orow;
+                        }
+                    }
+                    store16(dst + (((long)tile * GROUPS + gq) * p.t_ld + lane) * 8, make_uint4(w4[0], w4[1], w4[2], w4[3]));
+                }
+            } else {
+                constexpr int PPX = OUT_B / 16;               // 16-byte pieces per pixel
+                T* obase = reinterpret_cast<T*>(p.out) + (OUT_B / 2) * (j - (MODE == PWDW_NONE && p.qT ? p.t_chunks : 0));
+#pragma unroll
+                for (int k = 0; k < (FR_OR * FR_OC * PPX + 511) / 512; ++k) {
+                    const int i = tid + 512 * k;              // (output pixel, piece)
+                    const int px = i / PPX, part = i - px * PPX;
+                    const int orow = px / FR_OC, ocol = px - orow * FR_OC;
+                    const int gy = ty0 + orow, gx = tx0 + ocol;
+                    if (px < FR_OR * FR_OC && gy < p.H && gx < p.W) {
+                        const char* src = obuf + px * OSTR + 16 * part;
+                        const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 8);
+                        store16(obase + ((long)gy * p.W + gx) * p.ldo + 8 * part, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                    }
+                }
+            }
+            FW_PH(7);
+            if constexpr (MODE == PWDW_GATE_MUL) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    if (jj == j) cs[jj] += cj;
+            }
+        }
+    }
+#ifdef FW_FRONT_STAMP
+    if ((blockIdx.x == 3 || blockIdx.x == 131) && lane == 0 && (wave == 0 || wave == 5))
+        printf("front-mfma cg=%d mode %d wg %d wave %d tiles %ld total %llu | A %llu gemm %llu B1 %llu ywrite %llu B2 %llu dw+out %llu B3 %llu store %llu\n", CG, MODE,
+               (int)blockIdx.x, wave, (long)(t_hi - t_lo), __builtin_amdgcn_s_memtime() - t_begin, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7]);
+#endif
+
+    // ---- SCA pooling: fixed-order wave reduction of the lanes' sums -> partial[workgroup][c] ------------------------------------
+    if constexpr (MODE == PWDW_GATE_MUL) {
+        if (p.partial) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j >= nch) break;
+                f32x4 v = cs[j];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += __shfl_xor(v[i], o);
+                if (lane == 0) *reinterpret_cast<f32x4*>(p.partial + (long)blockIdx.x * (32 * nch) + 32 * j + 4 * wave) = v;
+            }
+        }
+    }
+}
+
 static int front_cus() {
     static int n = [] {
         int dev = 0, v = 0;
@@ -389,9 +749,18 @@ void launch_pw_dw(DType dt, const PwDwParams& p, hipStream_t st) {
         (p.mode == PWDW_GATE_MUL && p.n_chunks > 4) || (p.qT && (p.mode != PWDW_NONE || p.t_chunks < 1 || p.t_chunks >= p.n_chunks || p.t_ld < 64 * p.t_chunks)))
         throw Error(1, "pw_dw: shape not eligible");
     dim3 grid((unsigned)pw_dw_blocks(p.H, p.W)), block(512);
+    // FW_PW_DW_MFMA=1: the depthwise phase on the matrix cores (pw_dw_mfma_kernel; not faster, see there); read per launch (tests flip
+    // it inside one process)
+    bool on_mfma = false;
+    if (const char* e = getenv("FW_PW_DW_MFMA")) on_mfma = atoi(e) != 0;
 #define FW_F(CG, MODE)                                                                            \
     do {                                                                                          \
-        if (dt == DT_BF16)                                                                        \
+        if (on_mfma) {                                                                            \
+            if (dt == DT_BF16)                                                                    \
+                hipLaunchKernelGGL((pw_dw_mfma_kernel<__bf16, CG, MODE>), grid, block, 0, st, p); \
+            else                                                                                  \
+                hipLaunchKernelGGL((pw_dw_mfma_kernel<_Float16, CG, MODE>), grid, block, 0, st, p); \
+        } else if (dt == DT_BF16)                                                                 \
             hipLaunchKernelGGL((pw_dw_kernel<__bf16, CG, MODE>), grid, block, 0, st, p);          \
         else                                                                                      \
             hipLaunchKernelGGL((pw_dw_kernel<_Float16, CG, MODE>), grid, block, 0, st, p);        \
@@ -445,6 +814,14 @@ size_t pack_pw_dw_blocks(DType dt, const float* w, const float* bias, const floa
             double a = bias ? bias[row] : 0.0;
             for (int k = 0; k < c; ++k) a += (double)w[(size_t)row * c + k] * ln_b[k];
             tail[10 * 64 + cc] = (float)a;
+            // the taps in the operand type for the matrix-core depthwise phase: per tap row {w1 << 16 | w0, w2}
+            uint32_t* t16 = reinterpret_cast<uint32_t*>(dst + (size_t)j * pb + (size_t)kcs * 4096 + FR_TAIL32) + cc * 6;
+            for (int dy = 0; dy < 3; ++dy) {
+                const uint32_t w0 = f32_to_operand(dt, wdw[(size_t)row * 9 + dy * 3]), w1 = f32_to_operand(dt, wdw[(size_t)row * 9 + dy * 3 + 1]),
+                               w2 = f32_to_operand(dt, wdw[(size_t)row * 9 + dy * 3 + 2]);
+                t16[2 * dy] = w0 | (w1 << 16);
+                t16[2 * dy + 1] = w2;
+            }
         }
     }
     return bytes;
