@@ -329,8 +329,8 @@ def main():
             nbytes = nafnet_design_bytes(H, W) if cfg == "tap" else ifnet_design_bytes(H, W)
             gbs = nbytes / (ms * 1e-3) / 1e9
             traffic, note = None, None
-            tf = newest_profile("traffic_tap.json")
-            if cfg == "tap" and tf is not None and (H, W) == (1080, 1920):
+            tf = newest_profile("traffic_tap.json" if cfg == "tap" else "traffic_rife.json")
+            if tf is not None and (H, W) == (1080, 1920):
                 tj = json.loads(tf.read_text())
                 if tj.get("lib_digest") == lib_digest() and tj.get("dtype") == args.dtype:
                     traffic = tj["hbm_bytes_per_forward"]

@@ -12,7 +12,7 @@ for c in sr tap rife restormer; do
 done
 cp $o/pmc_summary.json profiles/${R}_pmc_summary.json
 cp $o/${R}_traffic.json profiles/${R}_traffic.json
-cp $o/${R}_traffic_tap.json $o/${R}_traffic_restormer.json profiles/
+cp $o/${R}_traffic_tap.json $o/${R}_traffic_restormer.json $o/${R}_traffic_rife.json profiles/
 cp $o/power_trace.json profiles/${R}_power_trace.json
 cp $o/energy.json profiles/${R}_energy.json
 cp $o/energy_table.md profiles/${R}_energy_table.md

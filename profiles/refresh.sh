@@ -20,12 +20,15 @@ python3 profiles/pmc_summarize.py "$o/pmc" "$o/pmc_summary.json" || true
 # HBM traffic of one NAFNet 1080p forward and of one Restormer 512x512 tile (all kernels), for the `tap` bench line and DESIGN section 6
 bash "$root/profiles/pmc_pass_path.sh" "$o/pmc_tap/p1" tools/profile_nafnet.py FETCH_SIZE
 bash "$root/profiles/pmc_pass_path.sh" "$o/pmc_tap/p2" tools/profile_nafnet.py WRITE_SIZE
+bash "$root/profiles/pmc_pass_path.sh" "$o/pmc_rife/p1" tools/profile_ifnet.py FETCH_SIZE
+bash "$root/profiles/pmc_pass_path.sh" "$o/pmc_rife/p2" tools/profile_ifnet.py WRITE_SIZE
 bash "$root/profiles/pmc_pass_path.sh" "$o/pmc_restormer/p1" tools/profile_restormer.py FETCH_SIZE
 bash "$root/profiles/pmc_pass_path.sh" "$o/pmc_restormer/p2" tools/profile_restormer.py WRITE_SIZE
 cd "$root"
 python3 tools/make_traffic_path.py "$o/pmc_tap" profiles/${R}_traffic_tap.json 4 f16 > /dev/null
 python3 tools/make_traffic_path.py "$o/pmc_restormer" profiles/${R}_traffic_restormer.json 3 f16 > /dev/null
-cp profiles/${R}_traffic_tap.json profiles/${R}_traffic_restormer.json "$o/"
+python3 tools/make_traffic_path.py "$o/pmc_rife" profiles/${R}_traffic_rife.json 5 f16 > /dev/null
+cp profiles/${R}_traffic_tap.json profiles/${R}_traffic_restormer.json profiles/${R}_traffic_rife.json "$o/"
 python3 bench.py > "$o/bench_sr.json" 2> "$o/bench_sr.err"
 python3 bench.py --config rife > "$o/bench_rife.json" 2> "$o/bench_rife.err"
 python3 bench.py --config tap > "$o/bench_tap.json" 2> "$o/bench_tap.err"

@@ -300,19 +300,28 @@ __global__ __launch_bounds__(512, 2) void pw_dw_kernel(const PwDwParams p) {
                 const char* ych = ybuf + FR_PXB * (FR_HC + 1) + 2 * lane;
 #pragma unroll 1
                 for (int gq = wave; gq < GROUPS; gq += 8) {
-                    unsigned w4[4];
+                    // eight 2-byte reads issued back to back, then masked: a branch per read (pixels the tile does not have) made hipcc wait
+                    // out every read's latency in turn - 56 round trips per wave and chunk, a third of the qkv front (round 3)
+                    unsigned u[8], keep[8];
+                    int off[8];
                     int orow = (gq * 8) / FR_OC, ocol = gq * 8 - orow * FR_OC;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const bool ok = gq * 8 + e < FR_OR * FR_OC && ty0 + orow < p.H && tx0 + ocol < p.W;     // wave-uniform
-                        unsigned u = 0;
-                        if (ok) u = *reinterpret_cast<const unsigned short*>(ych + (orow * FR_HC + ocol) * FR_PXB);
-                        if (e & 1) w4[e >> 1] |= u << 16; else w4[e >> 1] = u;
+                        off[e] = ok ? (orow * FR_HC + ocol) * FR_PXB : 0;
+                        keep[e] = ok ? 0xffffu : 0u;
                         if (++ocol == FR_OC) {
                             ocol = 0;
                             ++orow;
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) u[e] = *reinterpret_cast<const unsigned short*>(ych + off[e]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    unsigned w4[4];
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) w4[e >> 1] = (u[e] & keep[e]) | ((u[e + 1] & keep[e + 1]) << 16);
                     store16(dst + (((long)tile * GROUPS + gq) * p.t_ld + lane) * 8, make_uint4(w4[0], w4[1], w4[2], w4[3]));
                 }
             } else {
@@ -657,19 +666,26 @@ __global__ __launch_bounds__(512, 2) void pw_dw_mfma_kernel(const PwDwParams p) 
                 const char* och = obuf + 2 * lane;
 #pragma unroll 1
                 for (int gq = wave; gq < GROUPS; gq += 8) {
-                    unsigned w4[4];
+                    unsigned u[8], keep[8];
+                    int off[8];
                     int orow = (gq * 8) / FR_OC, ocol = gq * 8 - orow * FR_OC;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const bool ok = gq * 8 + e < FR_OR * FR_OC && ty0 + orow < p.H && tx0 + ocol < p.W;     // wave-uniform
-                        unsigned u = 0;
-                        if (ok) u = *reinterpret_cast<const unsigned short*>(och + (orow * FR_OC + ocol) * OSTR);
-                        if (e & 1) w4[e >> 1] |= u << 16; else w4[e >> 1] = u;
+                        off[e] = ok ? (orow * FR_OC + ocol) * OSTR : 0;
+                        keep[e] = ok ? 0xffffu : 0u;
                         if (++ocol == FR_OC) {
                             ocol = 0;
                             ++orow;
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) u[e] = *reinterpret_cast<const unsigned short*>(och + off[e]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    unsigned w4[4];
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) w4[e >> 1] = (u[e] & keep[e]) | ((u[e + 1] & keep[e + 1]) << 16);
                     store16(dst + (((long)tile * GROUPS + gq) * p.t_ld + lane) * 8, make_uint4(w4[0], w4[1], w4[2], w4[3]));
                 }
             } else {
