@@ -127,7 +127,11 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_pair_slid
     const int t_lo = (int)((long)lb * ntiles / NB);
     const int t_hi = (int)((long)(lb + 1) * ntiles / NB);
     if (t_lo >= t_hi) return;
+#ifdef FW_PS_NOWARM   // timing only (wrong pixels in the first conv_b row of a run that starts mid-column): what the warm-up tiles cost
+    const int needs_warm = 0;
+#else
     const int needs_warm = (t_lo % tiles_y) != 0;  // the run starts below the top of a column: conv_a of the tile above first
+#endif
     const int t_begin = t_lo - needs_warm;
     const int na = p.na;
     const int nitems = (t_hi - t_lo) * (na + 1) + needs_warm * na;
