@@ -259,6 +259,19 @@ int fw_resize_lanczos4_u16(const uint16_t* src, int src_h, int src_w, int channe
                            void* stream);
 
 /* -------------------------------------------------------------------------------------------------
+ * The host arithmetic of AESRGANFaceRestorer around its network
+ * replaces  `cv2.resize(enhanced_face, (target_w, target_h))` and the feathered float32 blend of `_paste_face_back`,
+ *           processors/aesrgan_face.py:543-584 (the network itself: fw_aesrgan_*).  Device pointers.
+ * fw_resize_linear_u8: cv2.resize with its default INTER_LINEAR on 8-bit images - OpenCV's fixed-point bilinear (11-bit coefficients,
+ * clamped borders), its 2 x 2 "area fast" average for an exact 2:1 decimation (the default upscale_factor), a copy at equal size;
+ * synchronises `stream` when it had to build tables.
+ * fw_face_paste_u8: frame[y1:y2, x1:x2] = orig * (1 - mask * s) + enhanced * mask * s in float32 with the reference's feather mask
+ * (min(w, h) // 8 rows / columns scaled by i / feather), truncating cast; `enhanced` is (y2 - y1) x (x2 - x1) x 3; in place. */
+int fw_resize_linear_u8(const uint8_t* src, int src_h, int src_w, int channels, uint8_t* dst, int dst_h, int dst_w, void* stream);
+int fw_face_paste_u8(uint8_t* frame, int height, int width, int x1, int y1, int x2, int y2, const uint8_t* enhanced, double strength,
+                     void* stream);
+
+/* -------------------------------------------------------------------------------------------------
  * Restormer building blocks (the reference's DEFAULT TAP model)
  * replaces  `Restormer(dim=48, num_blocks=[4,6,6,8], num_refinement_blocks=4, heads=[1,2,4,8],
  *           ffn_expansion_factor=2.66, bias=False, LayerNorm_type='WithBias')` + `self._model(tensor)`

@@ -531,6 +531,63 @@ def assign_frames_logic() -> None:
     print("wrote tests/golden/assign_frames.json;", len(cases), "cases")
 
 
+def face_restorer_logic() -> None:
+    """Fixture set 9 - the host side of AESRGANFaceRestorer (reference src/framewright/processors/aesrgan_face.py:51-136, 270-760):
+    the interfaces (fields, defaults, method parameters, enum values, validation messages, class constants) read off the reference's
+    own classes, and `_extract_face` RUN on the reference's own instance (pure index arithmetic: no cv2 needed).  `_paste_face_back`
+    and the detectors call cv2, which this image does not have: they cannot be run, their restatement (oracle/face_ref.py) stays
+    unpinned.  -> tests/golden/face_reference.json"""
+    import dataclasses
+    import enum
+    import inspect
+    import json
+    import tempfile
+    a = load_reference("framewright.processors.aesrgan_face")
+
+    def describe(cls):
+        d = {"methods": {}}
+        for name, fn in inspect.getmembers(cls, predicate=inspect.isfunction):
+            if name.startswith("__") and name != "__init__":
+                continue
+            d["methods"][name] = list(inspect.signature(fn).parameters)
+        for name, prop in inspect.getmembers(cls, lambda o: isinstance(o, property)):
+            d["methods"][name] = ["<property>"]
+        if dataclasses.is_dataclass(cls):
+            fields = {}
+            for f in dataclasses.fields(cls):
+                v = f.default if f.default is not dataclasses.MISSING else "<required>"
+                if isinstance(v, enum.Enum):
+                    v = v.value
+                fields[f.name] = v if isinstance(v, (int, float, str, bool, type(None))) else repr(v)
+            d["fields"] = fields
+        return d
+
+    out = {"classes": {n: describe(getattr(a, n)) for n in ("AESRGANFaceConfig", "FaceBox", "AESRGANFaceResult", "AESRGANFaceRestorer", "FaceDetector")},
+           "FaceDetectorType": {m.name: m.value for m in a.FaceDetectorType},
+           "constants": {"MODEL_FILE": a.AESRGANFaceRestorer.MODEL_FILE, "DEFAULT_MODEL_DIR_tail": list(a.AESRGANFaceRestorer.DEFAULT_MODEL_DIR.parts[-3:])},
+           "factory_params": list(inspect.signature(a.create_aesrgan_restorer).parameters), "validate": {}, "extract": []}
+    for kw in ({}, {"detection_threshold": 1.5}, {"enhancement_strength": -0.1}, {"upscale_factor": 3}, {"face_detector": "opencv"}, {"upscale_factor": 4}):
+        try:
+            c = a.AESRGANFaceConfig(**kw)
+            out["validate"][json.dumps(kw, sort_keys=True)] = {"ok": True, "face_detector": c.face_detector.value}
+        except Exception as e:  # noqa: BLE001
+            out["validate"][json.dumps(kw, sort_keys=True)] = {"ok": False, "error": f"{type(e).__name__}: {e}"}
+    with tempfile.TemporaryDirectory() as td:
+        r = a.AESRGANFaceRestorer(a.AESRGANFaceConfig(), model_dir=Path(td))
+        out["backend_without_opencv"] = r._backend          # the reference disables itself without cv2: None
+        rng = np.random.default_rng(5)
+        for (h, w, box, pad) in [(120, 160, (40, 30, 100, 90), 0.3), (120, 160, (0, 0, 50, 40), 0.3), (120, 160, (130, 90, 160, 120), 0.3),
+                                 (64, 48, (10, 12, 31, 45), 0.5), (64, 48, (5, 5, 6, 6), 0.3), (200, 300, (100, 50, 223, 181), 0.0)]:
+            frame = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+            fb = a.FaceBox(x1=box[0], y1=box[1], x2=box[2], y2=box[3], confidence=0.9)
+            crop, region = r._extract_face(frame, fb, padding=pad)
+            out["extract"].append({"h": h, "w": w, "box": list(box), "padding": pad, "region": [int(v) for v in region], "crop_shape": list(crop.shape),
+                                   "crop_sum": int(crop.astype(np.int64).sum()), "width": fb.width, "height": fb.height, "center": list(fb.center),
+                                   "frame_seed_index": len(out["extract"])})
+    (ROOT / "tests" / "golden" / "face_reference.json").write_text(json.dumps(out, indent=1, sort_keys=True))
+    print("wrote tests/golden/face_reference.json;", len(out["extract"]), "extract cases; backend without cv2:", out["backend_without_opencv"])
+
+
 if __name__ == "__main__":
     main()
     host_logic()
@@ -541,3 +598,4 @@ if __name__ == "__main__":
     aesrgan_attention()
     interpolator_logic()
     gpu_distributor_logic()
+    face_restorer_logic()

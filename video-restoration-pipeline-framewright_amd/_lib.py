@@ -40,7 +40,7 @@ EXPORTS = [
     "fw_u8_to_nhwc", "fw_pixel_shuffle_add_u8",
     "fw_layernorm_nhwc", "fw_pack_pointwise", "fw_pointwise_nhwc", "fw_dwconv3x3_nhwc", "fw_attn_workspace_floats",
     "fw_attn_matrix", "fw_attn_apply", "fw_attn_pack", "fw_attn_proj_pack", "fw_pixel_shuffle2_f32", "fw_copy_channels_f32", "fw_f32_to_planar", "fw_tap_post_u8",
-    "fw_flow_accumulate_u8", "fw_flow_accumulate_finish_u8", "fw_resize_lanczos4_u8", "fw_grain_addback_u8", "fw_attn_softmax_rows", "fw_pack_pointwise_transposed", "fw_attn_qk_scratch_elems", "fw_attn_matrix_mfma",
+    "fw_flow_accumulate_u8", "fw_flow_accumulate_finish_u8", "fw_resize_lanczos4_u8", "fw_resize_linear_u8", "fw_face_paste_u8", "fw_grain_addback_u8", "fw_attn_softmax_rows", "fw_pack_pointwise_transposed", "fw_attn_qk_scratch_elems", "fw_attn_matrix_mfma",
 ]
 
 
@@ -123,6 +123,10 @@ def _declare_tap(lib: C.CDLL) -> None:
     lib.fw_grain_addback_u8.argtypes = [vp, vp, i32, i32, f64, vp, vp, vp]
     lib.fw_resize_lanczos4_u8.restype = i32
     lib.fw_resize_lanczos4_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp]
+    lib.fw_resize_linear_u8.restype = i32
+    lib.fw_resize_linear_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp]
+    lib.fw_face_paste_u8.restype = i32
+    lib.fw_face_paste_u8.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, f64, vp]
 
 
 def _declare_ifnet(lib: C.CDLL) -> None:

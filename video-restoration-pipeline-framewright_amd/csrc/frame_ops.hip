@@ -644,6 +644,138 @@ void launch_resize_lanczos4_u16(const uint16_t* src, int Hs, int Ws, int C, uint
     FW_HIP_CHECK(e2);
 }
 
+// ---- cv2.resize(img, (w, h)) with the default interpolation (INTER_LINEAR) on 8-bit images ------------------------------------
+// `_paste_face_back` of the reference's AESRGANFaceRestorer (src/framewright/processors/aesrgan_face.py:553) brings the enhanced crop
+// back to the size of its region with it.  OpenCV's 8-bit path (imgproc/resize.cpp; restated in oracle/face_ref.py, parity unpinned:
+// no cv2 in the image): an exact 2 x 2 decimation - the default upscale_factor 2 - takes the "area fast" path, (a + b + c + d + 2) >> 2;
+// everything else is the fixed-point bilinear: 11-bit coefficients from float fx = (dx + 0.5) * scale - 0.5, both borders clamped
+// with fx = 0, the horizontal sums kept as ints, the vertical pass (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.
+__global__ __launch_bounds__(256) void resize_area2_u8_kernel(const uint8_t* __restrict__ src, int Ws, int C, uint8_t* __restrict__ dst, int Hd,
+                                                              int Wd) {
+    const long total = (long)Hd * Wd * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long px = i / C;
+        const int dy = (int)(px / Wd), dx = (int)(px - (long)dy * Wd);
+        const uint8_t* s0 = src + ((long)(2 * dy) * Ws + 2 * dx) * C + c;
+        const uint8_t* s1 = s0 + (long)Ws * C;
+        dst[i] = (uint8_t)(((int)s0[0] + (int)s0[C] + (int)s1[0] + (int)s1[C] + 2) >> 2);
+    }
+}
+
+__global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __restrict__ src, int Hs, int Ws, int C, uint8_t* __restrict__ dst,
+                                                               int Hd, int Wd, const int* __restrict__ xofs, const short* __restrict__ ialpha,
+                                                               const int* __restrict__ yofs, const short* __restrict__ ibeta) {
+    const long total = (long)Hd * Wd;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int dy = (int)(i / Wd), dx = (int)(i - (long)dy * Wd);
+        const int sx = xofs[dx], sy = yofs[dy];
+        const int sx1 = sx + 1 < Ws ? sx + 1 : Ws - 1, sy1 = sy + 1 < Hs ? sy + 1 : Hs - 1;
+        const int a0 = ialpha[2 * dx], a1 = ialpha[2 * dx + 1], b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
+        const uint8_t* r0 = src + (long)sy * Ws * C;
+        const uint8_t* r1 = src + (long)sy1 * Ws * C;
+        for (int c = 0; c < C; ++c) {
+            const int h0 = (int)r0[sx * C + c] * a0 + (int)r0[sx1 * C + c] * a1;
+            const int h1 = (int)r1[sx * C + c] * a0 + (int)r1[sx1 * C + c] * a1;
+            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            dst[i * C + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+}
+
+static void linear_tables(int ssize, int dsize, std::vector<int>& ofs, std::vector<short>& coef) {
+    const double inv_scale = (double)dsize / ssize, scale = 1. / inv_scale;
+    ofs.resize(dsize);
+    coef.resize((size_t)dsize * 2);
+    for (int d = 0; d < dsize; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s0 = (int)std::floor(f);
+        f -= s0;
+        if (s0 < 0) f = 0.f, s0 = 0;
+        if (s0 >= ssize - 1) f = 0.f, s0 = ssize - 1;
+        ofs[d] = s0;
+        coef[(size_t)d * 2] = (short)std::lrintf((1.f - f) * 2048.f);   // saturate_cast<short>: round to nearest even; |c| <= 2048
+        coef[(size_t)d * 2 + 1] = (short)std::lrintf(f * 2048.f);
+    }
+}
+
+void launch_resize_linear_u8(const uint8_t* src, int Hs, int Ws, int C, uint8_t* dst, int Hd, int Wd, hipStream_t st) {
+    const long total = (long)Hd * Wd;
+    const int blocks = (int)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
+    if (Hs == Hd && Ws == Wd) {
+        FW_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)total * C, hipMemcpyDeviceToDevice, st));
+        return;
+    }
+    if (Ws == 2 * Wd && Hs == 2 * Hd) {
+        hipLaunchKernelGGL(resize_area2_u8_kernel, dim3(blocks), dim3(256), 0, st, src, Ws, C, dst, Hd, Wd);
+        FW_HIP_CHECK(hipGetLastError());
+        return;
+    }
+    std::vector<int> xofs, yofs;
+    std::vector<short> ia, ib;
+    linear_tables(Ws, Wd, xofs, ia);
+    linear_tables(Hs, Hd, yofs, ib);
+    const size_t nx = (size_t)Wd, ny = (size_t)Hd;
+    const size_t bytes = (nx + ny) * 4 + (nx + ny) * 4;   // [xofs | yofs | ialpha | ibeta]
+    char* d = nullptr;
+    FW_HIP_CHECK(hipMalloc((void**)&d, bytes));
+    std::vector<char> h(bytes);
+    memcpy(h.data(), xofs.data(), nx * 4);
+    memcpy(h.data() + nx * 4, yofs.data(), ny * 4);
+    memcpy(h.data() + (nx + ny) * 4, ia.data(), nx * 4);
+    memcpy(h.data() + (nx + ny) * 4 + nx * 4, ib.data(), ny * 4);
+    hipError_t e = hipMemcpyAsync(d, h.data(), bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(resize_linear_u8_kernel, dim3(blocks), dim3(256), 0, st, src, Hs, Ws, C, dst, Hd, Wd, reinterpret_cast<const int*>(d),
+                           reinterpret_cast<const short*>(d + (nx + ny) * 4), reinterpret_cast<const int*>(d + nx * 4),
+                           reinterpret_cast<const short*>(d + (nx + ny) * 4 + nx * 4));
+        e = hipGetLastError();
+    }
+    // the tables live in pageable host memory and a per-call device block: finish before both go away (a face region per call)
+    const hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    FW_HIP_CHECK(e);
+    FW_HIP_CHECK(e2);
+}
+
+// ---- the blend of `_paste_face_back` (aesrgan_face.py:556-584), float32 statement for statement -----------------------------------
+// mask = 1, then for i < feather = min(w, h) // 8: rows i and h-1-i and columns i and w-1-i are multiplied by float32(i / feather)
+// (i / feather in double); region = orig * (1 - mask * s) + enh * mask * s in float32 (no FMA: this file is built with
+// -ffp-contract=off), truncating cast.  `frame` is updated in place inside [y1, y2) x [x1, x2).
+__global__ __launch_bounds__(256) void face_paste_u8_kernel(uint8_t* frame, int W, int x1, int y1, int rw, int rh, const uint8_t* __restrict__ enh,
+                                                            float s, int feather) {
+    const long total = (long)rh * rw;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / rw), x = (int)(i - (long)y * rw);
+        float m = 1.0f;
+        if (feather > 0) {
+            if (y < feather) m = m * (float)((double)y / (double)feather);
+            if (y >= rh - feather) m = m * (float)((double)(rh - 1 - y) / (double)feather);
+            if (x < feather) m = m * (float)((double)x / (double)feather);
+            if (x >= rw - feather) m = m * (float)((double)(rw - 1 - x) / (double)feather);
+        }
+        const float t2 = 1.0f - m * s;
+        uint8_t* o = frame + ((long)(y1 + y) * W + (x1 + x)) * 3;
+        const uint8_t* e = enh + i * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float a = (float)o[c] * t2;
+            const float b = ((float)e[c] * m) * s;
+            o[c] = (uint8_t)(int)(a + b);
+        }
+    }
+}
+
+void launch_face_paste_u8(uint8_t* frame, int H, int W, int x1, int y1, int x2, int y2, const uint8_t* enh, float strength, hipStream_t st) {
+    const int rw = x2 - x1, rh = y2 - y1;
+    if (rw <= 0 || rh <= 0 || x1 < 0 || y1 < 0 || x2 > W || y2 > H) throw Error(1, "face_paste: region outside the frame");
+    const int feather = (rw < rh ? rw : rh) / 8;
+    const long total = (long)rw * rh;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(face_paste_u8_kernel, dim3(blocks), dim3(256), 0, st, frame, W, x1, y1, rw, rh, enh, strength, feather);
+    FW_HIP_CHECK(hipGetLastError());
+}
+
 // ---- grain add-back (reference src/framewright/processors/tap_denoise.py:621-632, :1015-1023) -------------------------
 //   gray = cv2.cvtColor(orig, COLOR_BGR2GRAY); blurred = cv2.GaussianBlur(gray, (0, 0), 3); grain = cv2.subtract(gray, blurred)
 //   denoised = cv2.add(denoised, (GRAY2BGR(grain) * factor).astype(np.uint8))

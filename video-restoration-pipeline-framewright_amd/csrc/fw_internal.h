@@ -275,6 +275,8 @@ void launch_grain_addback(const uint8_t* orig, const uint8_t* den, int H, int W,
                           hipStream_t st);
 // cv2.resize(INTER_LANCZOS4) on 8-bit H x W x C images (device pointers); synchronises the stream
 void launch_resize_lanczos4_u8(const uint8_t* src, int Hs, int Ws, int C, uint8_t* dst, int Hd, int Wd, hipStream_t st);
+void launch_resize_linear_u8(const uint8_t* src, int Hs, int Ws, int C, uint8_t* dst, int Hd, int Wd, hipStream_t st);
+void launch_face_paste_u8(uint8_t* frame, int H, int W, int x1, int y1, int x2, int y2, const uint8_t* enh, float strength, hipStream_t st);
 // the same on 16-bit images (OpenCV's float path for ushort); synchronises the stream
 void launch_resize_lanczos4_u16(const uint16_t* src, int Hs, int Ws, int C, uint16_t* dst, int Hd, int Wd, hipStream_t st);
 void launch_flow_accumulate_finish(const double* acc, const double* wsum, long n, uint8_t* out, hipStream_t st);

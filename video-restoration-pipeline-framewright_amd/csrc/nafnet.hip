@@ -677,6 +677,19 @@ int fw_resize_lanczos4_u16(const uint16_t* src, int src_h, int src_w, int channe
     return guarded([&] { launch_resize_lanczos4_u16(src, src_h, src_w, channels, dst, dst_h, dst_w, (hipStream_t)stream); });
 }
 
+int fw_resize_linear_u8(const uint8_t* src, int src_h, int src_w, int channels, uint8_t* dst, int dst_h, int dst_w, void* stream) {
+    if (!src || !dst || src_h < 1 || src_w < 1 || dst_h < 1 || dst_w < 1 || channels < 1 || channels > 4)
+        return fail(FW_ERR_INVALID, "fw_resize_linear_u8: bad argument");
+    return guarded([&] { launch_resize_linear_u8(src, src_h, src_w, channels, dst, dst_h, dst_w, (hipStream_t)stream); });
+}
+
+int fw_face_paste_u8(uint8_t* frame, int height, int width, int x1, int y1, int x2, int y2, const uint8_t* enhanced, double strength,
+                     void* stream) {
+    if (!frame || !enhanced || height < 1 || width < 1 || !(strength >= 0.0) || strength > 1.0)
+        return fail(FW_ERR_INVALID, "fw_face_paste_u8: bad argument");
+    return guarded([&] { launch_face_paste_u8(frame, height, width, x1, y1, x2, y2, enhanced, (float)strength, (hipStream_t)stream); });
+}
+
 int fw_nafnet_destroy(fw_nafnet* n) {
     if (!n) return FW_OK;
     { std::lock_guard<std::mutex> lk(n->mu); }   // a call in flight on another thread finishes first
