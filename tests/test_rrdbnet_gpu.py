@@ -534,3 +534,21 @@ def test_thread_pool_on_one_shared_upsampler_with_an_injected_oom(hip_lib, tmp_p
             assert "memory" in err.lower()
     del up
     R.clear_upsampler_cache()
+
+
+def test_gfpgan_background_upsampler(hip_lib, tmp_path, monkeypatch):
+    """`FaceRestorer._get_bg_upsampler` (face_restore.py:379-401) hands GFPGAN a RealESRGANer(scale=4, x4plus, tile=400, tile_pad=10,
+    pre_pad=0, half=True) or None: the drop-in shares the x4plus engine of `get_upsampler` but keeps its own tiling."""
+    monkeypatch.setenv("FRAMEWRIGHT_AMD_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("FRAMEWRIGHT_MODEL_DIR", str(tmp_path / "none"))
+    R.clear_upsampler_cache()
+    assert R.get_bg_upsampler(None) is None and R.get_bg_upsampler("none") is None and R.get_bg_upsampler("") is None
+    bg = R.get_bg_upsampler("realesrgan")
+    main = R.get_upsampler(R.PyTorchESRGANConfig(model_name="RealESRGAN_x4plus", scale_factor=4, tile_size=0))
+    assert isinstance(bg, R.HipRealESRGANer) and bg.engine is main.engine
+    assert (bg.scale, bg.tile_size, bg.tile_pad, bg.pre_pad, bg.half) == (4, 400, 10, 0, True) and main.tile_size == 0
+    frame = synthetic_frames(1, 40, 56, seed=5)[0]
+    a, mode = bg.enhance(frame, outscale=4)
+    b, _ = main.enhance(frame, outscale=4)
+    assert mode == "RGB" and a.shape == (160, 224, 3) and np.array_equal(a, b)      # below the tile size: one whole-frame forward
+    R.clear_upsampler_cache()

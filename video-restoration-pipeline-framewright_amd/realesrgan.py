@@ -445,6 +445,21 @@ def get_upsampler(config: PyTorchESRGANConfig) -> HipRealESRGANer:
         return up
 
 
+def get_bg_upsampler(bg_upsampler: Optional[str] = "realesrgan", gpu_id: int = 0, dtype: str = "f16") -> Optional[HipRealESRGANer]:
+    """The background upsampler GFPGAN is handed by the reference's face restorer (``FaceRestorer._get_bg_upsampler``,
+    processors/face_restore.py:379-401): ``None`` for no / ``'none'`` upsampler, else ``RealESRGANer(scale=4, model_path=
+    'RealESRGAN_x4plus.pth', model=RRDBNet(3, 3, 64, 23, 32, scale=4), tile=400, tile_pad=10, pre_pad=0, half=True)`` - here the
+    x4plus engine of `get_upsampler` behind an upsampler object of its own (its tiling must not follow the frame upscaler's).  Like the
+    reference it answers ``None`` instead of raising when the upsampler cannot be built."""
+    if not bg_upsampler or bg_upsampler == "none":
+        return None
+    try:
+        base = get_upsampler(PyTorchESRGANConfig(model_name="RealESRGAN_x4plus", scale_factor=4, gpu_id=gpu_id, dtype=dtype))
+        return HipRealESRGANer(4, base.engine, tile=400, tile_pad=10, pre_pad=0, half=True, gpu_id=gpu_id)
+    except Exception:   # noqa: BLE001 - face_restore.py:399-400
+        return None
+
+
 def _imread(path: Path) -> Optional[np.ndarray]:
     try:
         import cv2  # the reference's reader (pytorch_realesrgan.py:198)
