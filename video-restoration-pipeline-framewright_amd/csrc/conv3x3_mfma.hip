@@ -261,8 +261,8 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
             // 8 channels of its two rows' pixels - consumed after the item's MFMAs: no LDS, no halo.  The loads go out from slot
             // FW_RES_SLOT of the item, BEHIND its two DMA batches (slots FW_DMA_SLOT_W / _A): hipcc waits for its own loads with
             // vmcnt(0), which also sits out every LDS-DMA issued after them - issued at the top of the item (round 2) that wait
-            // drained the prefetch of the next item at the end of every residual item (rdb3's conv5: 4 of 6 items; 3.4 ms per frame,
-            // gpurun_out/r03/ab4.log); issued last, the DMAs in front of them have had the item's MFMAs to land.
+            // drained the prefetch of the next item at the end of every residual item (rdb3's conv5: 4 of 6 items; measured in round 3,
+            // DESIGN.md section 6.3); issued last, the DMAs in front of them have had the item's MFMAs to land.
             uint4 idx[RPW][2];
             const bool has_id = SPLIT && c < p.n_id;
             auto load_residual = [&]() {

@@ -598,7 +598,7 @@ __global__ __launch_bounds__(512, 2) void pw_dw_mfma_kernel(const PwDwParams p) 
                 // registers shifted by one / two lanes within the 16-lane row (v_mov_b32 row_shl: lane n takes lane n + dy; lanes past the
                 // row get zero - they belong to output rows 14, 15, which the 14-row tile does not have).  Reading row n + dy from LDS
                 // instead made the phase LDS-bound: 48 KiB-reads per wave and chunk, ~4.0k cycles per chunk against the VALU phase's 5.3k
-                // (without the gate; gpurun_out/r03/stamps_*.log).
+                // (without the gate; profiles/r03_ab/pw_dw_mfma.txt).
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
                     uint4 A[3];
