@@ -320,53 +320,66 @@ class AESRGANFaceRestorer:
         y2 = min(h, face_box.y2 + pad_h)
         return frame[y1:y2, x1:x2].copy(), (x1, y1, x2, y2)
 
-    def _enhance_face_device(self, face_crop: np.ndarray):
-        """uint8 BGR crop -> uint8 BGR CUDA tensor, upscale_factor times larger: BGR -> RGB, / 255, the network,
-        ``clip(y * 255, 0, 255)`` and a TRUNCATING cast (aesrgan_face.py:519-541)."""
+    def _enhance_face_device(self, face_crop):
+        """uint8 BGR crop (numpy array or CUDA tensor) -> uint8 BGR CUDA tensor, upscale_factor times larger: BGR -> RGB, / 255, the
+        network, ``clip(y * 255, 0, 255)`` and a TRUNCATING cast (aesrgan_face.py:519-541)."""
         import torch
         eng = self._model
         with eng._mu, torch.cuda.device(eng._dev):
-            x = torch.from_numpy(np.ascontiguousarray(face_crop[:, :, ::-1])).to(eng._dev).float() / 255.0
+            t = face_crop if isinstance(face_crop, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(face_crop)).to(eng._dev)
+            x = t.flip(2).float() / 255.0
             y = eng.forward_rgb(x)
             return (y * 255.0).clamp_(0, 255).to(torch.uint8).flip(2).contiguous()
 
     def _enhance_face(self, face_crop: np.ndarray) -> np.ndarray:
         return self._enhance_face_device(face_crop).cpu().numpy()
 
-    def _paste_face_back(self, frame: np.ndarray, enhanced_face, region: Tuple[int, int, int, int]) -> np.ndarray:
-        """``cv2.resize(enhanced, (w, h))`` + the feathered float32 blend (aesrgan_face.py:543-584) on the device."""
+    def _paste_device(self, d, enhanced, region: Tuple[int, int, int, int]) -> None:
+        """``cv2.resize(enhanced, (w, h))`` + the feathered float32 blend (aesrgan_face.py:543-584), in place on the CUDA frame ``d``."""
         import torch
         lib, eng = _lib.load(), self._model
         x1, y1, x2, y2 = region
         th, tw = y2 - y1, x2 - x1
+        st = C.c_void_p(torch.cuda.current_stream(eng._dev).cuda_stream)
+        resized = torch.empty((th, tw, 3), dtype=torch.uint8, device=eng._dev)
+        _lib.check(lib.fw_resize_linear_u8(C.c_void_p(enhanced.data_ptr()), int(enhanced.shape[0]), int(enhanced.shape[1]), 3, C.c_void_p(resized.data_ptr()), th, tw, st))
+        _lib.check(lib.fw_face_paste_u8(C.c_void_p(d.data_ptr()), int(d.shape[0]), int(d.shape[1]), x1, y1, x2, y2, C.c_void_p(resized.data_ptr()),
+                                        float(self.config.enhancement_strength), st))
+
+    def _paste_face_back(self, frame: np.ndarray, enhanced_face, region: Tuple[int, int, int, int]) -> np.ndarray:
+        """The reference's method on host arrays: a new frame with the enhanced face blended into ``region``."""
+        import torch
+        eng = self._model
         with torch.cuda.device(eng._dev):
             enh = enhanced_face if isinstance(enhanced_face, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(enhanced_face)).to(eng._dev)
-            st = C.c_void_p(torch.cuda.current_stream(eng._dev).cuda_stream)
-            resized = torch.empty((th, tw, 3), dtype=torch.uint8, device=eng._dev)
-            _lib.check(lib.fw_resize_linear_u8(C.c_void_p(enh.data_ptr()), int(enh.shape[0]), int(enh.shape[1]), 3, C.c_void_p(resized.data_ptr()), th, tw, st))
             d = torch.from_numpy(np.ascontiguousarray(frame)).to(eng._dev)
-            _lib.check(lib.fw_face_paste_u8(C.c_void_p(d.data_ptr()), int(frame.shape[0]), int(frame.shape[1]), x1, y1, x2, y2,
-                                            C.c_void_p(resized.data_ptr()), float(self.config.enhancement_strength), st))
+            self._paste_device(d, enh.contiguous(), region)
             return d.cpu().numpy()
 
     def restore_frame(self, frame: np.ndarray) -> Tuple[np.ndarray, int]:
-        """aesrgan_face.py:586-626."""
+        """aesrgan_face.py:586-626.  The frame goes to the device once: every face is cropped from the running result there (a later
+        face sees the earlier ones pasted in, as in the reference), enhanced, resized and blended in place, and the result comes back
+        once."""
+        import torch
         if self._model is None or self._face_detector is None:
             self._load_model()
         faces = self._face_detector.detect(frame)
         faces = [f for f in faces if f.confidence >= self.config.detection_threshold]
         if not faces:
             return frame, 0
-        result = frame.copy()
-        for face_box in faces:
-            try:
-                face_crop, region = self._extract_face(result, face_box)
-                enhanced_face = self._enhance_face_device(face_crop)
-                if self.config.paste_back:
-                    result = self._paste_face_back(result, enhanced_face, region)
-            except Exception as e:   # noqa: BLE001 - like the reference: a face that fails is skipped
-                logger.warning("Failed to enhance face: %s", e)
-                continue
+        eng = self._model
+        with torch.cuda.device(eng._dev):
+            d = torch.from_numpy(np.ascontiguousarray(frame)).to(eng._dev)
+            for face_box in faces:
+                try:
+                    _, (x1, y1, x2, y2) = self._extract_face(frame, face_box)          # the region: index arithmetic only
+                    enhanced_face = self._enhance_face_device(d[y1:y2, x1:x2].contiguous())
+                    if self.config.paste_back:
+                        self._paste_device(d, enhanced_face, (x1, y1, x2, y2))
+                except Exception as e:   # noqa: BLE001 - like the reference: a face that fails is skipped
+                    logger.warning("Failed to enhance face: %s", e)
+                    continue
+            result = d.cpu().numpy() if self.config.paste_back else frame.copy()
         return result, len(faces)
 
     def restore_faces(self, input_dir: Path, output_dir: Path, progress_callback: Optional[Callable[[float], None]] = None) -> AESRGANFaceResult:
