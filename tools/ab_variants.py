@@ -56,7 +56,7 @@ print(json.dumps({"ms_per_frame": ms, "conv_tflops": conv_flops / conv_ms / 1e9,
 def rebuild(srcdir: Path, flags: list[str]) -> None:
     cc = B.hipcc()
     B.build()  # the other objects
-    for name in ("conv3x3_mfma", "conv3x3_pair", "conv3x3_pair_slide", "conv3x3_pair_slide32", "conv_up2x_phase"):
+    for name in ("conv3x3_mfma", "conv3x3_pair", "conv3x3_pair_slide", "conv3x3_pair_slide32", "conv_up2x_phase", "conv3x3_wino"):
         src = srcdir / f"{name}.hip"
         if not src.exists():
             src = B.CSRC / f"{name}.hip"

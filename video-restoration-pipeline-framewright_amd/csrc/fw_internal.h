@@ -98,6 +98,10 @@ struct ConvPairParams {
     const void* zeros;     // set by launch_conv3x3_pair
     unsigned long long* stamps;  // diagnostic builds only (-DFW_PAIR_STAMP)
 };
+// conv5 of a dense block (64 output channels, the split-trunk residuals) as a row-wise Winograd F(2, 3) (conv3x3_wino.hip; f16 only):
+// the ConvParams of launch_conv3x3(dt, 2, EPI_RESIDUAL_SPLIT, ...) with wpk = pack_conv3x3_wino_weights' fragments.
+size_t pack_conv3x3_wino_weights(DType dt, const float* w, int cout, int cin, int cin_chunks, uint16_t* dst);
+void launch_conv3x3_wino_split(const ConvParams& p, hipStream_t stream);
 void launch_conv3x3_pair(DType dt, const ConvPairParams& p, hipStream_t stream);
 const void* conv_zero_page();  // 256 B of zeros on the current device
 

@@ -23,6 +23,7 @@ struct ConvLayer {
     void* d_w = nullptr;
     float* d_b = nullptr;
     void* d_wphase = nullptr;   // conv_up1 / conv_up2: the same weights as four 2x2 phase convolutions (conv_up2x_phase.hip)
+    void* d_wwino = nullptr;    // conv5 of a dense block, f16: the same weights as row-wise Winograd fragments (conv3x3_wino.hip)
     bool set = false;
 };
 
@@ -66,6 +67,8 @@ struct fw_rrdbnet {
     // conv_up1 / conv_up2 (nearest x2 + 3x3) as four 2x2 phase convolutions on the source grid: 4 instead of 9 taps per output pixel
     // (FW_RRDB_UP_PHASE=0 keeps the gathering nine-tap form, for A/B runs)
     bool up_phase = true;
+    // conv5 of rdb1 / rdb2 (no residual planes) as a row-wise Winograd F(2, 3): two thirds of the MFMAs (FW_RRDB_C5_WINO=1, f16 only)
+    bool c5_wino = false;
     int abl_rdb3 = 0;   // TIMING-ONLY ablation of rdb3's conv5 (wrong pixels): 1 no lo write, 2 no R lo planes, 4 no R hi planes (FW_RRDB_ABL_RDB3)
     // hipGraph capture of the per-frame forward (BASELINE configs[4] "hipGraph-captured per-frame stages").  graph_mode: 0 never
     // (default), 1 always, 2 for frames of at most graph_max_px input pixels.  Off by default because it buys nothing here: the
@@ -194,7 +197,9 @@ void free_layer(ConvLayer& l) {
     if (l.d_w) (void)hipFree(l.d_w);
     if (l.d_b) (void)hipFree(l.d_b);
     if (l.d_wphase) (void)hipFree(l.d_wphase);
+    if (l.d_wwino) (void)hipFree(l.d_wwino);
     l.d_wphase = nullptr;
+    l.d_wwino = nullptr;
     l.d_w = nullptr;
     l.d_b = nullptr;
     l.set = false;
@@ -375,7 +380,27 @@ void forward(fw_rrdbnet* n, const void* d_in, int bits, int H, int W, void* d_ou
                     }
                 }
                 p.s1 = (k == 2) ? 0.2f * 0.2f : 0.2f;
-                run_conv(n, L[4], EPI_RESIDUAL_SPLIT, p, st);
+                if (n->c5_wino && n->dt == DT_F16 && p.n_id == 0 && L[4].d_wwino && !(n->abl_alias & 2)) {
+                    p.cin_chunks = L[4].chunks;
+                    p.wpk = L[4].d_wwino;
+                    p.bias = L[4].d_b;
+                    if (n->profile) {
+                        if (n->ev_used + 2 > n->ev_pool.size()) {
+                            size_t old = n->ev_pool.size();
+                            n->ev_pool.resize(old + 1024);
+                            for (size_t i = old; i < n->ev_pool.size(); ++i) FW_HIP_CHECK(hipEventCreate(&n->ev_pool[i]));
+                        }
+                        FW_HIP_CHECK(hipEventRecord(n->ev_pool[n->ev_used++], st));
+                        launch_conv3x3_wino_split(p, st);
+                        FW_HIP_CHECK(hipEventRecord(n->ev_pool[n->ev_used++], st));
+                        n->prof_flops += conv_flops(L[4], (size_t)p.H * p.W);   // algorithmic: the nine-tap count
+                        n->prof_stream = st;
+                    } else {
+                        launch_conv3x3_wino_split(p, st);
+                    }
+                } else {
+                    run_conv(n, L[4], EPI_RESIDUAL_SPLIT, p, st);
+                }
             } else {
                 p.res1 = (k == 0) ? Rin : (k == 1 ? tA : tB);
                 if (k == 2) {
@@ -514,6 +539,7 @@ int fw_rrdbnet_create(int device_id, int num_block, int scale, int dtype, fw_rrd
         if (const char* e = getenv("FW_RRDB_ABL_ALIAS")) n->abl_alias = atoi(e);
         if (const char* e = getenv("FW_RRDB_UP_PHASE")) n->up_phase = atoi(e) != 0;
         if (const char* e = getenv("FW_RRDB_ABL_RDB3")) n->abl_rdb3 = atoi(e);
+        if (const char* e = getenv("FW_RRDB_C5_WINO")) n->c5_wino = atoi(e) != 0;
         *out = n.release();
     });
 }
@@ -544,6 +570,13 @@ int fw_rrdbnet_set_conv(fw_rrdbnet* n, const char* key, const float* weight, con
         FW_HIP_CHECK(hipMalloc((void**)&l->d_b, b.size() * 4));
         FW_HIP_CHECK(hipMemcpy(l->d_w, packed.data(), ne * 2, hipMemcpyHostToDevice));
         FW_HIP_CHECK(hipMemcpy(l->d_b, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+        if (n->dt == DT_F16 && cout == 64 && cin == 192) {   // a dense block's conv5
+            const size_t nw = pack_conv3x3_wino_weights(n->dt, nullptr, cout, cin, l->chunks, nullptr);
+            std::vector<uint16_t> wn(nw);
+            pack_conv3x3_wino_weights(n->dt, weight, cout, cin, l->chunks, wn.data());
+            FW_HIP_CHECK(hipMalloc(&l->d_wwino, nw * 2));
+            FW_HIP_CHECK(hipMemcpy(l->d_wwino, wn.data(), nw * 2, hipMemcpyHostToDevice));
+        }
         if (l == &n->conv_up1 || l == &n->conv_up2) {
             const size_t np = pack_conv_up2x_phase_weights(n->dt, nullptr, nullptr);
             std::vector<uint16_t> ph(np);
