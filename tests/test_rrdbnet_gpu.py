@@ -554,22 +554,23 @@ def test_gfpgan_background_upsampler(hip_lib, tmp_path, monkeypatch):
     R.clear_upsampler_cache()
 
 
+@pytest.mark.parametrize("wino", ["1", "2"])
 @pytest.mark.parametrize("num_block,scale,H,W", [(23, 4, 40, 56), (6, 4, 33, 47), (23, 2, 41, 57), (4, 4, 96, 150)])
-def test_winograd_conv5_vs_oracle_and_vs_the_direct_kernel(hip_lib, monkeypatch, num_block, scale, H, W):
+def test_winograd_conv5_vs_oracle_and_vs_the_direct_kernel(hip_lib, monkeypatch, num_block, scale, H, W, wino):
     """conv5 of rdb1 / rdb2 as a row-wise Winograd F(2, 3) (conv3x3_wino.hip, FW_RRDB_C5_WINO=1: transformed weights rounded to f16 once,
     pixel differences formed in f16): the same 1e-3 / 60 dB bar against the fp32 oracle as the direct kernels, and within rounding of
     them (ragged sizes, odd widths, several tiles per workgroup row)."""
     sd = synthetic_rrdbnet_state(num_block, scale, seed=1234)
     frame = synthetic_frames(1, H, W, seed=H * W)[0]
     outs = {}
-    for mode in ("1", "0"):
+    for mode in (wino, "0"):        # "1": conv5 of rdb1 / rdb2, "2": rdb3's as well (residual planes R hi, R lo in frequencies 0 / 3)
         monkeypatch.setenv("FW_RRDB_C5_WINO", mode)
         eng = R.RRDBNetEngine(num_block, scale, "f16")
         eng.load_state_dict(sd)
         outs[mode] = _gpu_rgb_f32(eng, frame)
         eng.close()
     want = _oracle_rgb_f32(sd, frame, num_block, scale)
-    (rgb, u8), (rgb_d, u8_d) = outs["1"], outs["0"]
+    (rgb, u8), (rgb_d, u8_d) = outs[wino], outs["0"]
     err, err_d = np.abs(rgb - want).max(), np.abs(rgb_d - want).max()
     print(f"nb={num_block} x{scale} {H}x{W}: winograd {err:.2e}, direct {err_d:.2e}, between them {np.abs(rgb - rgb_d).max():.2e}")
     assert not np.array_equal(rgb, rgb_d)                      # the knob took effect

@@ -42,8 +42,9 @@ def add(name, us, alg, exe):
 tiles_pair = 64 * 68          # 30-column tiles: ceil(1920 / 30) x (1080 + 16) // 16
 warm = 192                    # 3 of the 4 workgroups of a column start mid-column: conv_a of the tile above, by one wave (1/16 of a tile's conv_a)
 for fr in frames:
-    body = [k for k in fr if "pair_slide" in k[0] or "Li2ELi3" in k[0]]
-    rest = [k for k in fr if not ("pair_slide" in k[0] or "Li2ELi3" in k[0])]
+    is_body = lambda nm: "pair_slide" in nm or "Li2ELi3" in nm or "wino_split" in nm
+    body = [k for k in fr if is_body(k[0])]
+    rest = [k for k in fr if not is_body(k[0])]
     for i, (nm, d) in enumerate(body):
         m = i % 3
         if m < 2:
@@ -56,8 +57,9 @@ for fr in frames:
             alg = gflop(192, 64)
             tiles5 = 60 * 68
             ident = (2 + (4 if rdb3 else 0)) * 8 / (6 * 144.0)      # identity MFMAs per tile and wave against 6 x 144 conv MFMAs
-            exe = alg * (tiles5 * 512) / px * (1 + ident)
-            add("conv5 of rdb3 (+ R hi, R lo; writes hi + lo)" if rdb3 else "conv5 of rdb1 / rdb2", d / 1e3, alg, exe)
+            wino = "wino_split" in nm                               # row-wise Winograd F(2, 3): 96 instead of 144 MFMAs per item and wave
+            exe = alg * (tiles5 * 512) / px * ((2.0 / 3.0 if wino else 1.0) + ident)
+            add("conv5 of rdb3 (+ R hi, R lo; writes hi + lo)" if rdb3 else ("conv5 of rdb1 / rdb2, Winograd F(2, 3) rows" if wino else "conv5 of rdb1 / rdb2"), d / 1e3, alg, exe)
     names = ["u8 -> NHWC", "conv_first", "conv_body", "conv_up1 (phase)", "conv_up2 (phase)", "conv_hr", "conv_last"]
     algs = [0, gflop(3, 64), gflop(64, 64), gflop(64, 64, 4 * px), gflop(64, 64, 16 * px), gflop(64, 64, 16 * px), gflop(64, 3, 16 * px)]
     exes = [0, gflop(32, 64), gflop(64, 64), gflop(64, 64, 4 * px) * 4 / 9, gflop(64, 64, 16 * px) * 4 / 9, gflop(64, 64, 16 * px), gflop(64, 32, 16 * px)]

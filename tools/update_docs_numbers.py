@@ -71,15 +71,16 @@ for l in et.split("\n"):
         tbl[c[0]] = c
 m = re.search(r"frame: ([\d.]+) ms of kernels.*bench ([\d.]+) ms -> ([\d.]+) J per frame, ([\d.]+) pJ", et.strip().split("\n")[-1])
 g = lambda n: tbl[n]
-p12, p34, c5a, c5b = g("pair conv1+conv2"), g("pair conv3+conv4"), g("conv5 of rdb1 / rdb2"), g("conv5 of rdb3 (+ R hi, R lo; writes hi + lo)")
+c5name = "conv5 of rdb1 / rdb2, Winograd F(2, 3) rows" if "conv5 of rdb1 / rdb2, Winograd F(2, 3) rows" in tbl else "conv5 of rdb1 / rdb2"
+p12, p34, c5a, c5b = g("pair conv1+conv2"), g("pair conv3+conv4"), g(c5name), g("conv5 of rdb3 (+ R hi, R lo; writes hi + lo)")
 first, body, up1, up2, hr, last = g("conv_first"), g("conv_body"), g("conv_up1 (phase)"), g("conv_up2 (phase)"), g("conv_hr"), g("conv_last")
 f = float
 new = f'''| launch class | per frame | ms | avg launch µs | of MFMA peak | executed / algorithmic MACs | J | pJ per algorithmic FLOP |
 |---|---|---|---|---|---|---|---|
 | pair conv1+conv2 (`conv3x3_pair_slide_kernel`) | 69 | {p12[2]} | {p12[3]} | {p12[4]} | {p12[5]} | {p12[6]} | {p12[7]} |
 | pair conv3+conv4 | 69 | {p34[2]} | {p34[3]} | {p34[4]} | {p34[5]} | {p34[6]} | {p34[7]} |
-| conv5 of rdb1 / rdb2 (`conv3x3_mfma_kernel<2, split>`) | 46 | {c5a[2]} | {c5a[3]} | **{c5a[4]}** | {c5a[5]} | {c5a[6]} | {c5a[7]} |
-| conv5 of rdb3 (+ R hi, R lo; writes hi + lo) | 23 | {c5b[2]} | {c5b[3]} | {c5b[4]} | {c5b[5]} | {c5b[6]} | {c5b[7]} |
+| conv5 of rdb1 / rdb2 (`conv3x3_wino_split_kernel`: row-wise Winograd F(2, 3)) | 46 | {c5a[2]} | {c5a[3]} | **{c5a[4]}** | {c5a[5]} | {c5a[6]} | {c5a[7]} |
+| conv5 of rdb3 (`conv3x3_mfma_kernel<2, split>`; + R hi, R lo; writes hi + lo) | 23 | {c5b[2]} | {c5b[3]} | {c5b[4]} | {c5b[5]} | {c5b[6]} | {c5b[7]} |
 | conv_first / conv_body | 2 | {f(first[2]) + f(body[2]):.2f} | – | – | – | {f(first[6]) + f(body[6]):.1f} | – |
 | conv_up1 / conv_up2 as four 2×2 phase convs | 2 | {f(up1[2]) + f(up2[2]):.2f} | – | {up1[4]} / {up2[4]} | 0.444 | {f(up1[6]) + f(up2[6]):.1f} | {up2[7]} |
 | conv_hr | 1 | {hr[2]} | {hr[3]} | {hr[4]} | 1.000 | {hr[6]} | {hr[7]} |

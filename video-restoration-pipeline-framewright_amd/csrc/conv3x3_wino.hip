@@ -189,6 +189,9 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_wino_spli
         constexpr int F = decltype(freq_tag)::value;
 #pragma unroll
         for (int ctl = 0; ctl < 2; ++ctl) {
+            // (the empty asm keeps hipcc from building every identity fragment of the kernel once and holding them all - they are loop
+            // invariant: 16 to 64 registers at the pressure peak)
+            asm volatile("" : "+v"(sc));
             float e[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) e[k] = ((id_mask >> (8 * ctl + k)) & 1u) ? sc : 0.f;
@@ -202,6 +205,27 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_wino_spli
                 else
                     acc[row][F][ctl] = Op<T>::mfma16(idf, xf[row], acc[row][F][ctl]);
             }
+        }
+    };
+
+    // the same for ONE of the wave's rows
+    auto add_identity1 = [&](int row, const uint4& xf, float sc, int c2, auto freq_tag) {
+        constexpr int F = decltype(freq_tag)::value;
+#pragma unroll
+        for (int ctl = 0; ctl < 2; ++ctl) {
+            // (the empty asm keeps hipcc from building every identity fragment of the kernel once and holding them all - they are loop
+            // invariant: 16 to 64 registers at the pressure peak)
+            asm volatile("" : "+v"(sc));
+            float e[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[k] = ((id_mask >> (8 * ctl + k)) & 1u) ? sc : 0.f;
+            const uint2 lo4 = Op<T>::pack4(e[0], e[1], e[2], e[3]);
+            const uint2 hi4 = Op<T>::pack4(e[4], e[5], e[6], e[7]);
+            const uint4 idf = make_uint4(lo4.x, lo4.y, hi4.x, hi4.y);
+            if (c2)
+                acc[row][F][2 + ctl] = Op<T>::mfma16(idf, xf, acc[row][F][2 + ctl]);
+            else
+                acc[row][F][ctl] = Op<T>::mfma16(idf, xf, acc[row][F][ctl]);
         }
     };
 
@@ -226,6 +250,22 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_wino_spli
             }
         }
 
+        // PLANES: byte offsets of the lane's residual fragments inside a plane (output rows 2 wave + row, columns 2j + e, slot sl), clamped
+        // into the image; bit 2 row + e of ro_ok says whether the pixel exists (a fragment outside is zeroed after its load)
+        unsigned ro[RPW][2];
+        unsigned ro_ok = 0;
+        if constexpr (PLANES) {
+#pragma unroll
+            for (int row = 0; row < RPW; ++row)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int y = y0 + RPW * wave + row, x = x0 + 2 * j + e;
+                    const int cy = y < p.H ? y : p.H - 1, cx = x < p.W ? x : p.W - 1;
+                    ro[row][e] = (unsigned)((((long)cy * p.W + cx) * p.in_cstride + 8 * sl) * 2);
+                    ro_ok |= (unsigned)(y < p.H && x < p.W) << (2 * row + e);
+                }
+        }
+
         for (int c = 0; c < nch; ++c, ++n) {
             // item n has landed: each wave waits for its own DMAs, then the barrier.  A tile's first item after an epilogue does not wait
             // (vmcnt counts stores too; its DMAs were waited for ahead of the epilogue's stores).
@@ -233,7 +273,6 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_wino_spli
             __syncthreads();
             // ---- the wave's four halo rows -> 16 transformed fragments; the raw centre columns of its two output rows for x hi ------------
             uint4 V[4][4];
-            uint4 xc0[RPW], xc1[RPW];
             const bool own = c < 2 && p.in_id_scale != 0.f;   // the conv's own input channels [32c, 32c + 32) are a residual too
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -243,15 +282,20 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_wino_spli
                 V[r][1] = wn_add(d1, d2);
                 V[r][2] = wn_sub(d2, d1);
                 V[r][3] = wn_sub(d1, d3);
-                if (r == 1 || r == 2) {
-                    xc0[r - 1] = d1;       // column 2j of output row r - 1
-                    xc1[r - 1] = d2;       // column 2j + 1
+                // x hi of output row r - 1 = the raw centre columns 2j (d1) and 2j + 1 (d2) of this halo row: added while they are in
+                // registers (kept until after the barrier they were 16 more registers at the kernel's pressure peak)
+                if ((r == 1 || r == 2) && own) {
+                    add_identity1(r - 1, d1, p.in_id_scale, c, std::integral_constant<int, 0>{});
+                    add_identity1(r - 1, d2, -p.in_id_scale, c, std::integral_constant<int, 3>{});
                 }
             }
             __syncthreads();   // every wave holds its fragments: the stage is free for the next item's DMA
             const bool more = n + 1 < nitems;
             const int c1 = (c + 1 == nch) ? 0 : c + 1;
-            if (more) {
+#ifndef FW_WN_DMA_K
+#define FW_WN_DMA_K -1      // K-loop step behind which the next item's two DMA batches go out (-1: ahead of the loop)
+#endif
+            if (FW_WN_DMA_K < 0 && more) {
                 issue_w(c1, (n + 1) & 1);
                 issue_act();
             }
@@ -261,13 +305,15 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_wino_spli
             // without a plane reads the zero page (no branch inside the loop).
             uint4 ix0[RPW], ix1[RPW];
             const bool has_id = PLANES && c < p.n_id;
-            if (own) {
-                add_identity(xc0, p.in_id_scale, c, std::integral_constant<int, 0>{});
-                add_identity(xc1, -p.in_id_scale, c, std::integral_constant<int, 3>{});
-            }
             // ---- 48 weight fragments, each feeding the wave's two rows ------------------------------------------------------------------
             const uint4* wl = lds + WN_ACT_REGION + (n & 1) * WN_W_REGION + lane;
-            constexpr int RING = 3;
+#ifndef FW_WN_RING
+#define FW_WN_RING 3
+#endif
+#ifndef FW_WN_RES_K
+#define FW_WN_RES_K 17     // K-loop step behind which the residual plane's four loads go out: the first halo row's fragments are dead from step 16 on
+#endif
+            constexpr int RING = FW_WN_RING;
             uint4 wf[RING];
 #pragma unroll
             for (int k = 0; k < RING - 1; ++k) wf[k] = wl[k * 64];
@@ -280,17 +326,18 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_wino_spli
                 acc[0][f][ct] = Op<T>::mfma16(wf[k % RING], V[dy][f], acc[0][f][ct]);
                 acc[1][f][ct] = Op<T>::mfma16(wf[k % RING], V[dy + 1][f], acc[1][f][ct]);
                 FW_SB();
+                if (k == FW_WN_DMA_K && more) {
+                    issue_w(c1, (n + 1) & 1);
+                    issue_act();
+                    FW_SB();
+                }
                 if constexpr (PLANES) {
-                    if (k == 33) {   // (addresses formed here, not held across the loop)
-                        const char* z = reinterpret_cast<const char*>(p.zeros);
-                        const char* plane = reinterpret_cast<const char*>(p.in) + (has_id ? p.chunk_off[c] : 0);
+                    if (k == FW_WN_RES_K) {   // wave-uniform base + per-lane 32-bit offsets; a chunk without a plane re-reads plane 0 (its fragments are not used)
+                        const char* plane = reinterpret_cast<const char*>(p.in) + p.chunk_off[has_id ? c : 0];
 #pragma unroll
                         for (int row = 0; row < RPW; ++row) {
-                            const int y = y0 + RPW * wave + row, x = x0 + 2 * j;
-                            const char* a0 = (has_id && y < p.H && x < p.W) ? plane + (((size_t)y * p.W + x) * p.in_cstride + 8 * sl) * 2 : z;
-                            const char* a1 = (has_id && y < p.H && x + 1 < p.W) ? plane + (((size_t)y * p.W + x + 1) * p.in_cstride + 8 * sl) * 2 : z;
-                            ix0[row] = *reinterpret_cast<const uint4*>(a0);
-                            ix1[row] = *reinterpret_cast<const uint4*>(a1);
+                            ix0[row] = *reinterpret_cast<const uint4*>(plane + ro[row][0]);
+                            ix1[row] = *reinterpret_cast<const uint4*>(plane + ro[row][1]);
                         }
                         FW_SB();
                     }
@@ -298,6 +345,11 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_wino_spli
             }
             if constexpr (PLANES) {
                 if (has_id) {
+#pragma unroll
+                    for (int row = 0; row < RPW; ++row) {
+                        if (!((ro_ok >> (2 * row)) & 1u)) ix0[row] = make_uint4(0, 0, 0, 0);
+                        if (!((ro_ok >> (2 * row + 1)) & 1u)) ix1[row] = make_uint4(0, 0, 0, 0);
+                    }
                     add_identity(ix0, p.id_scale[c], c & 1, std::integral_constant<int, 0>{});
                     add_identity(ix1, -p.id_scale[c], c & 1, std::integral_constant<int, 3>{});
                 }
@@ -378,10 +430,10 @@ void launch_conv3x3_wino_split(const ConvParams& p_in, hipStream_t stream) {
     const int tiles = ((p.W + TILE_W - 1) / TILE_W) * ((p.H + TILE_H - 1) / TILE_H);
     const int cus = conv_num_cus();
     dim3 grid(tiles < cus ? tiles : cus), block(64 * NWAVES);
-    // residual planes (rdb3's conv5) stay with the direct kernel: with their 16 fragment registers next to 128 accumulators and 64 transformed
-    // fragments hipcc spills 55 - 86 registers (PLANES = true is written and not instantiated)
-    if (p.n_id > 0) throw Error(1, "conv3x3_wino: residual planes are the direct kernel's (n_id must be 0)");
-    hipLaunchKernelGGL(conv3x3_wino_split_kernel<false>, grid, block, 0, stream, p);
+    if (p.n_id > 0)
+        hipLaunchKernelGGL(conv3x3_wino_split_kernel<true>, grid, block, 0, stream, p);
+    else
+        hipLaunchKernelGGL(conv3x3_wino_split_kernel<false>, grid, block, 0, stream, p);
     FW_HIP_CHECK(hipGetLastError());
 }
 

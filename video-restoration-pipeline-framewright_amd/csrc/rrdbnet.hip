@@ -67,8 +67,10 @@ struct fw_rrdbnet {
     // conv_up1 / conv_up2 (nearest x2 + 3x3) as four 2x2 phase convolutions on the source grid: 4 instead of 9 taps per output pixel
     // (FW_RRDB_UP_PHASE=0 keeps the gathering nine-tap form, for A/B runs)
     bool up_phase = true;
-    // conv5 of rdb1 / rdb2 (no residual planes) as a row-wise Winograd F(2, 3): two thirds of the MFMAs (FW_RRDB_C5_WINO=1, f16 only)
-    bool c5_wino = false;
+    // conv5 as a row-wise Winograd F(2, 3): two thirds of the MFMAs (f16 only; conv3x3_wino.hip).  FW_RRDB_C5_WINO: 0 never, 1 (default)
+    // rdb1 / rdb2 - no residual planes: 69.4 -> 67.6 ms per 1080p frame -, 2 rdb3 as well (its residual-plane variant spills 17 registers
+    // and is 1 ms SLOWER than the direct kernel there: profiles/r03_ab/conv5_winograd_rows.txt)
+    int c5_wino = 1;
     int abl_rdb3 = 0;   // TIMING-ONLY ablation of rdb3's conv5 (wrong pixels): 1 no lo write, 2 no R lo planes, 4 no R hi planes (FW_RRDB_ABL_RDB3)
     // hipGraph capture of the per-frame forward (BASELINE configs[4] "hipGraph-captured per-frame stages").  graph_mode: 0 never
     // (default), 1 always, 2 for frames of at most graph_max_px input pixels.  Off by default because it buys nothing here: the
@@ -380,7 +382,7 @@ void forward(fw_rrdbnet* n, const void* d_in, int bits, int H, int W, void* d_ou
                     }
                 }
                 p.s1 = (k == 2) ? 0.2f * 0.2f : 0.2f;
-                if (n->c5_wino && n->dt == DT_F16 && p.n_id == 0 && L[4].d_wwino && !(n->abl_alias & 2)) {
+                if (n->c5_wino && n->dt == DT_F16 && (p.n_id == 0 || n->c5_wino >= 2) && L[4].d_wwino && !(n->abl_alias & 2) && !n->abl_rdb3) {
                     p.cin_chunks = L[4].chunks;
                     p.wpk = L[4].d_wwino;
                     p.bias = L[4].d_b;
@@ -539,7 +541,7 @@ int fw_rrdbnet_create(int device_id, int num_block, int scale, int dtype, fw_rrd
         if (const char* e = getenv("FW_RRDB_ABL_ALIAS")) n->abl_alias = atoi(e);
         if (const char* e = getenv("FW_RRDB_UP_PHASE")) n->up_phase = atoi(e) != 0;
         if (const char* e = getenv("FW_RRDB_ABL_RDB3")) n->abl_rdb3 = atoi(e);
-        if (const char* e = getenv("FW_RRDB_C5_WINO")) n->c5_wino = atoi(e) != 0;
+        if (const char* e = getenv("FW_RRDB_C5_WINO")) n->c5_wino = atoi(e);
         *out = n.release();
     });
 }
