@@ -75,7 +75,8 @@ __device__ __forceinline__ void wn_glds_w6(const void* sbase, unsigned voff, uns
 }
 
 // PLANES: with residual planes from HBM (rdb3's conv5); without, their 16 fragment registers do not exist (rdb1 / rdb2: two thirds of the launches)
-template <bool PLANES>
+// STORE: the plain epilogue instead of the split trunk's - typed output of act(conv + bias) (conv_hr of the RRDBNet tail at 8K)
+template <bool PLANES, bool STORE>
 __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_wino_split_kernel(const ConvParams p) {
     using T = _Float16;
     __shared__ __attribute__((aligned(16))) uint4 lds[WN_TOTAL];
@@ -250,22 +251,6 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_wino_spli
             }
         }
 
-        // PLANES: byte offsets of the lane's residual fragments inside a plane (output rows 2 wave + row, columns 2j + e, slot sl), clamped
-        // into the image; bit 2 row + e of ro_ok says whether the pixel exists (a fragment outside is zeroed after its load)
-        unsigned ro[RPW][2];
-        unsigned ro_ok = 0;
-        if constexpr (PLANES) {
-#pragma unroll
-            for (int row = 0; row < RPW; ++row)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int y = y0 + RPW * wave + row, x = x0 + 2 * j + e;
-                    const int cy = y < p.H ? y : p.H - 1, cx = x < p.W ? x : p.W - 1;
-                    ro[row][e] = (unsigned)((((long)cy * p.W + cx) * p.in_cstride + 8 * sl) * 2);
-                    ro_ok |= (unsigned)(y < p.H && x < p.W) << (2 * row + e);
-                }
-        }
-
         for (int c = 0; c < nch; ++c, ++n) {
             // item n has landed: each wave waits for its own DMAs, then the barrier.  A tile's first item after an epilogue does not wait
             // (vmcnt counts stores too; its DMAs were waited for ahead of the epilogue's stores).
@@ -273,7 +258,7 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_wino_spli
             __syncthreads();
             // ---- the wave's four halo rows -> 16 transformed fragments; the raw centre columns of its two output rows for x hi ------------
             uint4 V[4][4];
-            const bool own = c < 2 && p.in_id_scale != 0.f;   // the conv's own input channels [32c, 32c + 32) are a residual too
+            const bool own = !STORE && c < 2 && p.in_id_scale != 0.f;   // the conv's own input channels [32c, 32c + 32) are a residual too
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const uint4* row = lds + (RPW * wave + r) * WN_ROWP;
@@ -336,8 +321,11 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_wino_spli
                         const char* plane = reinterpret_cast<const char*>(p.in) + p.chunk_off[has_id ? c : 0];
 #pragma unroll
                         for (int row = 0; row < RPW; ++row) {
-                            ix0[row] = *reinterpret_cast<const uint4*>(plane + ro[row][0]);
-                            ix1[row] = *reinterpret_cast<const uint4*>(plane + ro[row][1]);
+                            const int y = y0 + RPW * wave + row, x = x0 + 2 * j;
+                            const int cy = y < p.H ? y : p.H - 1, cx0 = x < p.W ? x : p.W - 1, cx1 = x + 1 < p.W ? x + 1 : p.W - 1;
+                            const unsigned rowb = (unsigned)cy * (unsigned)p.W;
+                            ix0[row] = *reinterpret_cast<const uint4*>(plane + ((rowb + cx0) * (unsigned)p.in_cstride + 8 * sl) * 2u);
+                            ix1[row] = *reinterpret_cast<const uint4*>(plane + ((rowb + cx1) * (unsigned)p.in_cstride + 8 * sl) * 2u);
                         }
                         FW_SB();
                     }
@@ -347,8 +335,9 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_wino_spli
                 if (has_id) {
 #pragma unroll
                     for (int row = 0; row < RPW; ++row) {
-                        if (!((ro_ok >> (2 * row)) & 1u)) ix0[row] = make_uint4(0, 0, 0, 0);
-                        if (!((ro_ok >> (2 * row + 1)) & 1u)) ix1[row] = make_uint4(0, 0, 0, 0);
+                        const int y = y0 + RPW * wave + row, x = x0 + 2 * j;
+                        if (!(y < p.H && x < p.W)) ix0[row] = make_uint4(0, 0, 0, 0);
+                        if (!(y < p.H && x + 1 < p.W)) ix1[row] = make_uint4(0, 0, 0, 0);
                     }
                     add_identity(ix0, p.id_scale[c], c & 1, std::integral_constant<int, 0>{});
                     add_identity(ix1, -p.id_scale[c], c & 1, std::integral_constant<int, 3>{});
@@ -359,7 +348,7 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_wino_spli
         // ---- epilogue: the next tile's first item is in flight: wait for it here, ahead of the stores ---------------------------------------
         FW_WAIT_VMCNT(0);
         const int ls = (sl & 1) ? 2 + (sl >> 1) : (sl >> 1);
-        const int npass = p.out_lo ? 2 : 1;
+        const int npass = (!STORE && p.out_lo) ? 2 : 1;
 #pragma unroll
         for (int row = 0; row < RPW; ++row) {
             const int y = y0 + RPW * wave + row;
@@ -367,8 +356,17 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_wino_spli
             // output transform into frequencies 0 (column 2j) and 3 (column 2j + 1)
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
-                const f32x4 ya = (acc[row][0][ct] + acc[row][1][ct] + acc[row][2][ct]) * p.s1;
-                const f32x4 yb = (acc[row][1][ct] - acc[row][2][ct] - acc[row][3][ct]) * p.s1;
+                f32x4 ya = acc[row][0][ct] + acc[row][1][ct] + acc[row][2][ct];
+                f32x4 yb = acc[row][1][ct] - acc[row][2][ct] - acc[row][3][ct];
+                if constexpr (STORE) {
+                    if (p.act == 1) {
+                        ya = lrelu4(ya);
+                        yb = lrelu4(yb);
+                    }
+                } else {
+                    ya = ya * p.s1;
+                    yb = yb * p.s1;
+                }
                 acc[row][0][ct] = ya;
                 acc[row][3][ct] = yb;
             }
@@ -431,9 +429,25 @@ void launch_conv3x3_wino_split(const ConvParams& p_in, hipStream_t stream) {
     const int cus = conv_num_cus();
     dim3 grid(tiles < cus ? tiles : cus), block(64 * NWAVES);
     if (p.n_id > 0)
-        hipLaunchKernelGGL(conv3x3_wino_split_kernel<true>, grid, block, 0, stream, p);
+        hipLaunchKernelGGL((conv3x3_wino_split_kernel<true, false>), grid, block, 0, stream, p);
     else
-        hipLaunchKernelGGL(conv3x3_wino_split_kernel<false>, grid, block, 0, stream, p);
+        hipLaunchKernelGGL((conv3x3_wino_split_kernel<false, false>), grid, block, 0, stream, p);
+    FW_HIP_CHECK(hipGetLastError());
+}
+
+// lrelu(conv3x3 + bias) (act = 1) or conv3x3 + bias, 64 output channels, typed planes out: the ConvParams of launch_conv3x3(dt, 2, EPI_STORE, ...)
+void launch_conv3x3_wino_store(const ConvParams& p_in, hipStream_t stream) {
+    ConvParams p = p_in;
+    p.zeros = conv_zero_page();
+    p.n_id = 0;
+    p.out_lo = nullptr;
+    if (p.H <= 0 || p.W <= 0 || p.cin_chunks <= 0 || p.upsample2x || !p.out || p.in_cstride < 32 || (p.in_cstride & 7) || (p.out_cstride & 7) || (p.out_coff & 7) ||
+        p.out_f32 || p.act > 1)
+        throw Error(1, "conv3x3_wino: bad problem");
+    const int tiles = ((p.W + TILE_W - 1) / TILE_W) * ((p.H + TILE_H - 1) / TILE_H);
+    const int cus = conv_num_cus();
+    dim3 grid(tiles < cus ? tiles : cus), block(64 * NWAVES);
+    hipLaunchKernelGGL((conv3x3_wino_split_kernel<false, true>), grid, block, 0, stream, p);
     FW_HIP_CHECK(hipGetLastError());
 }
 

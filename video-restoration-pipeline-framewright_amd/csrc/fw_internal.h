@@ -102,6 +102,7 @@ struct ConvPairParams {
 // the ConvParams of launch_conv3x3(dt, 2, EPI_RESIDUAL_SPLIT, ...) with wpk = pack_conv3x3_wino_weights' fragments.
 size_t pack_conv3x3_wino_weights(DType dt, const float* w, int cout, int cin, int cin_chunks, uint16_t* dst);
 void launch_conv3x3_wino_split(const ConvParams& p, hipStream_t stream);
+void launch_conv3x3_wino_store(const ConvParams& p, hipStream_t stream);   // act(conv + bias) -> typed planes (EPI_STORE, 64 channels)
 void launch_conv3x3_pair(DType dt, const ConvPairParams& p, hipStream_t stream);
 const void* conv_zero_page();  // 256 B of zeros on the current device
 

@@ -71,6 +71,7 @@ struct fw_rrdbnet {
     // rdb1 / rdb2 - no residual planes: 69.4 -> 67.6 ms per 1080p frame -, 2 rdb3 as well (its residual-plane variant spills 17 registers
     // and is 1 ms SLOWER than the direct kernel there: profiles/r03_ab/conv5_winograd_rows.txt)
     int c5_wino = 1;
+    bool hr_wino = false;   // conv_hr at the output resolution in the same form (FW_RRDB_HR_WINO=1)
     int abl_rdb3 = 0;   // TIMING-ONLY ablation of rdb3's conv5 (wrong pixels): 1 no lo write, 2 no R lo planes, 4 no R hi planes (FW_RRDB_ABL_RDB3)
     // hipGraph capture of the per-frame forward (BASELINE configs[4] "hipGraph-captured per-frame stages").  graph_mode: 0 never
     // (default), 1 always, 2 for frames of at most graph_max_px input pixels.  Off by default because it buys nothing here: the
@@ -482,7 +483,27 @@ void forward(fw_rrdbnet* n, const void* d_in, int bits, int H, int W, void* d_ou
         p.out = U3;
         p.out_pstride = 16 * PL;
         p.act = 1;
-        run_conv(n, n->conv_hr, EPI_STORE, p, st);
+        if (n->c5_wino && n->dt == DT_F16 && n->conv_hr.d_wwino && n->hr_wino) {
+            p.cin_chunks = n->conv_hr.chunks;
+            p.wpk = n->conv_hr.d_wwino;
+            p.bias = n->conv_hr.d_b;
+            if (n->profile) {
+                if (n->ev_used + 2 > n->ev_pool.size()) {
+                    size_t old = n->ev_pool.size();
+                    n->ev_pool.resize(old + 1024);
+                    for (size_t i = old; i < n->ev_pool.size(); ++i) FW_HIP_CHECK(hipEventCreate(&n->ev_pool[i]));
+                }
+                FW_HIP_CHECK(hipEventRecord(n->ev_pool[n->ev_used++], st));
+                launch_conv3x3_wino_store(p, st);
+                FW_HIP_CHECK(hipEventRecord(n->ev_pool[n->ev_used++], st));
+                n->prof_flops += conv_flops(n->conv_hr, (size_t)p.H * p.W);
+                n->prof_stream = st;
+            } else {
+                launch_conv3x3_wino_store(p, st);
+            }
+        } else {
+            run_conv(n, n->conv_hr, EPI_STORE, p, st);
+        }
     }
     {
         ConvParams p = base;
@@ -542,6 +563,7 @@ int fw_rrdbnet_create(int device_id, int num_block, int scale, int dtype, fw_rrd
         if (const char* e = getenv("FW_RRDB_UP_PHASE")) n->up_phase = atoi(e) != 0;
         if (const char* e = getenv("FW_RRDB_ABL_RDB3")) n->abl_rdb3 = atoi(e);
         if (const char* e = getenv("FW_RRDB_C5_WINO")) n->c5_wino = atoi(e);
+        if (const char* e = getenv("FW_RRDB_HR_WINO")) n->hr_wino = atoi(e) != 0;
         *out = n.release();
     });
 }
@@ -572,7 +594,7 @@ int fw_rrdbnet_set_conv(fw_rrdbnet* n, const char* key, const float* weight, con
         FW_HIP_CHECK(hipMalloc((void**)&l->d_b, b.size() * 4));
         FW_HIP_CHECK(hipMemcpy(l->d_w, packed.data(), ne * 2, hipMemcpyHostToDevice));
         FW_HIP_CHECK(hipMemcpy(l->d_b, b.data(), b.size() * 4, hipMemcpyHostToDevice));
-        if (n->dt == DT_F16 && cout == 64 && cin == 192) {   // a dense block's conv5
+        if (n->dt == DT_F16 && cout == 64 && (cin == 192 || l == &n->conv_hr)) {   // a dense block's conv5; conv_hr of the tail
             const size_t nw = pack_conv3x3_wino_weights(n->dt, nullptr, cout, cin, l->chunks, nullptr);
             std::vector<uint16_t> wn(nw);
             pack_conv3x3_wino_weights(n->dt, weight, cout, cin, l->chunks, wn.data());
