@@ -266,6 +266,11 @@ def main():
     warm = max(1, args.warmup)
     if cfg in ("tap", "chain") and world > 1:
         warm = max(warm, 2)        # a block holds at least window // 2 frames, in the warm-up pass too
+    if cfg != "sr":
+        # these passes hand back one output tensor per frame: the warm-up has to be one whole pass, or the first timed pass pays the
+        # hipMallocs behind torch's caching allocator (620 MB of mid frames on the rife line: 1.24 against 0.83 ms per pair -
+        # profiles/r03_ab/rife_output_buffers.txt) - a cost a clip pays once, not per pass.  `sr` writes into one buffer: W as given.
+        warm = max(warm, min(chunk, steps))
     run_steps(warm)
     torch.cuda.synchronize()
     barrier()
@@ -389,7 +394,7 @@ def main():
                   "tap": "frames/sec NAFNet temporal denoise 1080p (window 5)",
                   "chain": "frames/sec preset chain 1080p (input frames per second)"}[cfg]
         res = {
-            "metric": metric, "value": fps, "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "metric": metric, "value": fps, "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warm,
             "ms_per_step": wall_max / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workloads[cfg] + f", seeded synthetic weights, {steps} frames per GPU", "sharding": sharding},

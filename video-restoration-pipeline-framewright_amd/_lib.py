@@ -346,6 +346,19 @@ def on_tensor_device(fn):
     return wrapped
 
 
+def empty_like_many(frames) -> list:
+    """Output buffers for a batch of frames: ONE allocation cut into views when the frames agree in shape (the usual clip), else one
+    per frame.  A hipMalloc is a device-wide synchronisation: a hundred of them in front of a hundred forwards that are meant to
+    overlap on side streams serialise those streams (measured on the `rife` bench line: 1.21 - 1.40 ms per 1080p pair with one
+    allocation per mid frame on a cold allocator, 0.83 with the buffers in place - profiles/r03_ab/rife_output_buffers.txt)."""
+    import torch
+    frames = list(frames)
+    if len(frames) > 1 and all(f.shape == frames[0].shape and f.dtype == frames[0].dtype and f.device == frames[0].device for f in frames):
+        buf = torch.empty((len(frames),) + tuple(frames[0].shape), dtype=frames[0].dtype, device=frames[0].device)
+        return list(buf.unbind(0))
+    return [torch.empty_like(f) for f in frames]
+
+
 def side_streams(env_name: str, default: int) -> int:
     """How many forwards of one engine kind may be in flight on their own streams (with engine clones).  ``env_name`` overrides.
     Measured on MI355X / ROCm 7.2: up to three worker streams beside the caller's overlap as intended; with a fourth the work

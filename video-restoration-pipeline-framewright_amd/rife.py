@@ -135,7 +135,7 @@ class IFNetEngine:
         while len(ws) < k:
             ws.append({"engine": self if not ws else self.clone(), "stream": torch.cuda.Stream(device=self._dev)})
         main = torch.cuda.current_stream(self._dev)
-        outs = [torch.empty_like(a) for a, _ in pairs]
+        outs = _lib.empty_like_many([a for a, _ in pairs])     # one allocation: a hipMalloc per mid frame would serialise the streams
         start = torch.cuda.Event()
         start.record(main)          # inputs and output buffers are ready once the caller's stream gets here
         for i, (a, b) in enumerate(pairs):

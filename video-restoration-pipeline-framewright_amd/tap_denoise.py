@@ -453,7 +453,7 @@ class TAPDenoiser:
         device = frames[0].device
         workers = self._frame_workers(k, device)
         main = torch.cuda.current_stream(device)
-        outs = [torch.empty_like(f) for f in frames]
+        outs = _lib.empty_like_many(frames)
         start = torch.cuda.Event()
         start.record(main)           # the frames and the output buffers are ready once the caller's stream gets here
         for i, f in enumerate(frames):
