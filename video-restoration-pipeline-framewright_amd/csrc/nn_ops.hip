@@ -73,9 +73,10 @@ constexpr int PW_PX = 256;
 
 template <typename T, int CT, int MODE>
 __global__ __launch_bounds__(256, 2) void pointwise_mfma_kernel(const PointwiseParams p) {
-    __shared__ __attribute__((aligned(16))) uint4 lds_all[PW_PX * 4 + 2 * CT * 64];   // one array: the residual epilogue reuses all of it
-    uint4* const lds_a = lds_all;
-    uint4* const lds_w = lds_all + PW_PX * 4;
+    // two staging buffers (round 3: one barrier per chunk - chunk c + 1 is written while other waves still multiply chunk c; with one buffer
+    // and two barriers a chunk cost 2.9 us where a CU holds one workgroup, 64 chunks of the deepest 2x2 stride-2 conv took 189 us)
+    constexpr int PW_STAGE = PW_PX * 4 + 2 * CT * 64;
+    __shared__ __attribute__((aligned(16))) uint4 lds_all[2 * PW_STAGE];   // one array: the turned epilogues reuse it
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int n_tiles = (p.N_tiles + CT - 1) / CT;  // blocks along couts
@@ -153,8 +154,10 @@ __global__ __launch_bounds__(256, 2) void pointwise_mfma_kernel(const PointwiseP
             }
         }
     };
+    int nstage = 0;   // chunks staged so far: chunk n lives in buffer n & 1
     auto stage = [&](const uint4 (&v)[4], const uint4 (&wv)[NWV]) {
-        __syncthreads();
+        uint4* const lds_a = lds_all + (nstage & 1) * PW_STAGE;
+        uint4* const lds_w = lds_a + PW_PX * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + 256 * i;
@@ -166,9 +169,14 @@ __global__ __launch_bounds__(256, 2) void pointwise_mfma_kernel(const PointwiseP
             const int idx = tid + 256 * i;
             if (idx < 2 * CT * 64) lds_w[idx] = wv[i];
         }
+        // every wave has written chunk n and is done with the MFMAs of chunk n - 1; the writes of chunk n + 1 (other buffer) may start while
+        // slower waves multiply chunk n, those of chunk n + 2 (this buffer) come after the next barrier
         __syncthreads();
+        ++nstage;
     };
     auto mma = [&]() {
+        const uint4* const lds_a = lds_all + ((nstage - 1) & 1) * PW_STAGE;
+        const uint4* const lds_w = lds_a + PW_PX * 4;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             uint4 wf[CT];
@@ -204,60 +212,93 @@ __global__ __launch_bounds__(256, 2) void pointwise_mfma_kernel(const PointwiseP
     // The other inputs: chunk c + 1's loads (operand rows and weight fragments) are issued right after chunk c is staged, so they are
     // in flight while its MFMAs run (they used to be issued after them: load latency + MFMAs per chunk, exposed whenever a CU holds
     // one workgroup - the 16 k- and 4 k-pixel levels of Restormer, NAFNet's deep levels).
-    auto aload = [&](int c, uint4 (&v)[4]) {
+    // A loads in two steps (round 3): `aissue` only loads - raw bits, rows clamped to M - 1 so that no branch separates the loads - and
+    // `aconv` turns them into operand fragments (fp32 -> operand type, SCA scale, zeros behind M) when the chunk is staged.  With the
+    // conversion inside the load step every piece waited for its own loads: four exposed latencies per chunk (the deepest 2x2 stride-2
+    // conv of NAFNet, 64 chunks on one workgroup per CU: 2.9 us per chunk, 190 us), and the "prefetch" of the next chunk hid nothing.
+    // The per-pixel part of the addresses (64-bit divisions of the 2x2 gather) is computed once, not per chunk.
+    long arow[4];        // element offset of the piece's pixel row (2x2 gather: of the pixel's top-left source pixel)
+    bool aok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int px = (tid + 256 * i) >> 2;
+        long m = m0 + px;
+        aok[i] = m < p.M;
+        if (!aok[i]) m = p.M - 1;
+        if (p.gather2x2) {
+            const int Wo = p.Win >> 1;
+            const int y = (int)(m / Wo), x = (int)(m - (long)y * Wo);
+            arow[i] = ((long)(2 * y) * p.Win + 2 * x) * p.lda;
+        } else {
+            arow[i] = m * p.lda;
+        }
+    }
+    auto aoff = [&](int c, int i, int* kk_out) -> long {   // element offset of piece i of chunk c; *kk_out = its first channel (for a_scale)
+        int kk = c * 32 + (tid & 3) * 8;
+        long off = arow[i];
+        if (p.gather2x2) {
+            // 2x2 stride-2 conv: k = (dy*2+dx)*Cin + ci ; output pixel m = (y, x) of the half-size grid
+            const int sub = kk / p.Cin;
+            kk -= sub * p.Cin;
+            off += ((long)(sub >> 1) * p.Win + (sub & 1)) * p.lda;
+            *kk_out = c * 32 + (tid & 3) * 8;
+            return off + kk;
+        }
+        *kk_out = kk;
+        return off + kk;
+    };
+    auto aissue = [&](int c, uint4 (&q)[4][2]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            const int px = idx >> 2, s = idx & 3;
-            const long m = m0 + px;
-            v[i] = make_uint4(0, 0, 0, 0);
-            if (m < p.M) {
-                long row_off;
-                int kk = c * 32 + s * 8;
-                if (p.gather2x2) {
-                    // 2x2 stride-2 conv: k = (dy*2+dx)*Cin + ci ; output pixel m = (y, x) of the half-size grid
-                    const int Wo = p.Win >> 1;
-                    const int y = (int)(m / Wo), x = (int)(m - (long)y * Wo);
-                    const int sub = kk / p.Cin;
-                    kk -= sub * p.Cin;
-                    row_off = ((long)(2 * y + (sub >> 1)) * p.Win + (2 * x + (sub & 1))) * p.lda;
-                } else {
-                    row_off = m * p.lda;
-                }
-                float f[8];
-                if (p.a_f32) {
-                    const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.a) + row_off + kk);
-                    const f32x4 lo = src[0], hi = src[1];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        f[j] = lo[j];
-                        f[4 + j] = hi[j];
-                    }
-                    if (p.a_scale) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) f[j] *= p.a_scale[kk + j];
-                    }
-                    v[i] = pack8f<T>(f);
-                } else {
-                    v[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.a) + row_off + kk);
-                    if (p.a_scale) {
-                        unpack8f<T>(v[i], f);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) f[j] *= p.a_scale[kk + j];
-                        v[i] = pack8f<T>(f);
-                    }
-                }
+            int kk;
+            const long off = aoff(c, i, &kk);
+            if (p.a_f32) {
+                const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(p.a) + off);
+                q[i][0] = src[0];
+                q[i][1] = src[1];
+            } else {
+                q[i][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.a) + off);
             }
         }
     };
+    auto aconv = [&](int c, const uint4 (&q)[4][2], uint4 (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kk = c * 32 + (tid & 3) * 8;
+            float f[8];
+            if (p.a_f32) {
+                const f32x4 lo = __builtin_bit_cast(f32x4, q[i][0]), hi = __builtin_bit_cast(f32x4, q[i][1]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f[j] = lo[j];
+                    f[4 + j] = hi[j];
+                }
+                if (p.a_scale) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] *= p.a_scale[kk + j];
+                }
+                v[i] = pack8f<T>(f);
+            } else {
+                v[i] = q[i][0];
+                if (p.a_scale) {
+                    unpack8f<T>(v[i], f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] *= p.a_scale[kk + j];
+                    v[i] = pack8f<T>(f);
+                }
+            }
+            if (!aok[i]) v[i] = make_uint4(0, 0, 0, 0);
+        }
+    };
     if (!ln) {
-        uint4 v[4], wv[NWV];
-        aload(0, v);
+        uint4 q[4][2], v[4], wv[NWV];
+        aissue(0, q);
         wload(0, wv);
         for (int c = 0; c < chunks; ++c) {
+            aconv(c, q, v);
             stage(v, wv);
             if (c + 1 < chunks) {
-                aload(c + 1, v);
+                aissue(c + 1, q);
                 wload(c + 1, wv);
             }
             mma();
@@ -266,29 +307,59 @@ __global__ __launch_bounds__(256, 2) void pointwise_mfma_kernel(const PointwiseP
 
     // ---- epilogue: lane holds pixel (wave*64 + pt*32 + r), couts 32*tile + 8g + 4h + j ------------------------------
 #ifndef FW_PW_RES_DIRECT
-    if constexpr (MODE == PW_RESIDUAL) {
+    // (round 3: the fp32 store of the 2x2 stride-2 convs and the PixelShuffle + skip epilogue of the up convs take the same way out - straight
+    //  from the accumulators NAFNet's four down and four up convs, HBM-bound by construction, moved 2.1 / 2.7 TB/s)
+    constexpr bool TURNED = MODE == PW_RESIDUAL || MODE == PW_SHUFFLE_UP || MODE == PW_STORE;
+    if constexpr (TURNED) if (MODE != PW_STORE || (p.out_f32 && !p.out_typed)) {
         // The residual epilogue moves four times the bytes of the K loop at K = N (fp32 stream in and out against a typed operand),
         // and straight from the accumulator layout a wave-instruction touched 32 pixel rows with 32 bytes each.  Here each 32-pixel
         // x 32-channel accumulator tile is turned round in a wave-private LDS slice ([32][36] floats in the staging buffers the K
         // loop is done with; conflict-free 16-byte writes), after which 8 lanes own one pixel's 128 contiguous bytes: the stream is
         // read and written in whole cache lines.  The reads of a 32-pixel group are issued before its tiles are turned.
         __syncthreads();                                            // every wave is done with lds_a / lds_w
-        static_assert((PW_PX * 4 + 2 * CT * 64) * 16 >= 4 * 32 * 36 * 4, "staging buffers too small for the epilogue slices");
+        static_assert(2 * PW_STAGE * 16 >= 4 * 32 * 36 * 4, "staging buffers too small for the epilogue slices");
         float* slice = reinterpret_cast<float*>(lds_all) + wave * (32 * 36);
         const int piece = lane & 7, prow = lane >> 3;
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
             const long mg = m0 + wave * 64 + pt * 32;                 // first pixel of the group (wave-uniform)
             if (mg >= p.M) continue;
+            // where this lane's four pixels (rows prow + 8 i of the group) and its four channels of a tile live in the fp32 stream
+            long orow[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long m = mg + prow + 8 * i;
+                if constexpr (MODE == PW_SHUFFLE_UP) {
+                    const int Wl = p.Win;
+                    const long mm = m < p.M ? m : p.M - 1;
+                    const int y = (int)(mm / Wl), x = (int)(mm - (long)y * Wl);
+                    orow[i] = ((long)(2 * y) * (2 * Wl) + 2 * x) * p.ldf;      // sub-position (dy, dx) added per tile
+                } else {
+                    orow[i] = m * p.ldf;
+                }
+            }
+            auto ocol = [&](int tile) -> long {   // column offset of channel 32 tile + 4 piece (PW_SHUFFLE_UP: n = sub * Cup + co, Cup % 32 == 0)
+                const int n = 32 * tile + 4 * piece;
+                if constexpr (MODE == PW_SHUFFLE_UP) {
+                    const int Cup = p.N_tiles * 8;
+                    const int sub = n / Cup, co = n - sub * Cup;
+                    return ((long)(sub >> 1) * (2 * p.Win) + (sub & 1)) * p.ldf + co;
+                } else {
+                    return n;
+                }
+            };
             f32x4 rs[CT][4];
+            if constexpr (MODE != PW_STORE) {
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const int tile = bn * CT + ct;
-                if (tile >= p.N_tiles) continue;
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int tile = bn * CT + ct;
+                    if (tile >= p.N_tiles) continue;
+                    const long oc = ocol(tile);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const long m = mg + prow + 8 * i;
-                    rs[ct][i] = m < p.M ? *reinterpret_cast<const f32x4*>(p.res_f32 + m * p.ldf + 32 * tile + 4 * piece) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int i = 0; i < 4; ++i) {
+                        const long m = mg + prow + 8 * i;
+                        rs[ct][i] = m < p.M ? *reinterpret_cast<const f32x4*>(p.res_f32 + orow[i] + oc) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
                 }
             }
 #pragma unroll
@@ -296,8 +367,10 @@ __global__ __launch_bounds__(256, 2) void pointwise_mfma_kernel(const PointwiseP
                 const int tile = bn * CT + ct;
                 if (tile >= p.N_tiles) continue;
                 const int n = 32 * tile + 4 * piece;
+                const long oc = ocol(tile);
                 const f32x4 bs = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(p.chan_scale + n);
+                f32x4 sc = {1.f, 1.f, 1.f, 1.f};
+                if constexpr (MODE == PW_RESIDUAL) sc = *reinterpret_cast<const f32x4*>(p.chan_scale + n);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 v = {acc[pt][ct][4 * g], acc[pt][ct][4 * g + 1], acc[pt][ct][4 * g + 2], acc[pt][ct][4 * g + 3]};
@@ -312,9 +385,11 @@ __global__ __launch_bounds__(256, 2) void pointwise_mfma_kernel(const PointwiseP
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float o = a[j] + bs[j];
-                        of[j] = rs[ct][i][j] + o * sc[j];
+                        if constexpr (MODE == PW_RESIDUAL) of[j] = rs[ct][i][j] + o * sc[j];
+                        else if constexpr (MODE == PW_SHUFFLE_UP) of[j] = o + rs[ct][i][j];
+                        else of[j] = o;
                     }
-                    if (m < p.M) *reinterpret_cast<f32x4*>(p.out_f32 + m * p.ldf + n) = of;
+                    if (m < p.M) *reinterpret_cast<f32x4*>(p.out_f32 + orow[i] + oc) = of;
                 }
             }
         }
@@ -635,6 +710,7 @@ void launch_pointwise(DType dt, const PointwiseParams& p, hipStream_t st) {
         return;
     }
     if (p.mode == PW_GATE && (p.N_tiles & 1)) throw Error(1, "pointwise: gate needs an even number of cout tiles");
+    if (p.mode == PW_SHUFFLE_UP && (p.N_tiles & 3)) throw Error(1, "pointwise: PixelShuffle epilogue needs N % 128 == 0 (a 32-channel tile inside one sub-position)");
     if (p.gather2x2 && (p.Cin & 31)) throw Error(1, "pointwise: 2x2 gather needs Cin % 32 == 0");
     if (p.ln_w && (!p.ln_b || !p.a_f32 || p.gather2x2 || p.a_scale || p.K != 64 || p.lda != 64))
         throw Error(1, "pointwise: fused LayerNorm needs a plain fp32 [M][64] input");
