@@ -305,3 +305,32 @@ def test_narrow_output_groups_give_identical_frames(hip_lib, monkeypatch):
         outs.append(rgb.cpu())
         eng.close()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_split_trunk_of_the_64_channel_block_matches_the_fp32_trunk(hip_lib, monkeypatch):
+    """The full-resolution IFBlock (64 channels) carries its ResConv trunk as hi + lo operand-typed tensors with beta folded into the
+    weights (FW_IFNET_SPLIT_TRUNK, default on; csrc/ifnet.hip): against the fp32 trunk the frames differ by operand rounding of the
+    folded weights only, and both sit equally close to the fp32 oracle."""
+    sd = synthetic_ifnet_state(seed=2468, flow_gain=4.0)
+    H, W = 96, 160
+    fr = synthetic_frames(2, H, W, seed=31)
+    a, b = torch.from_numpy(fr[0]).cuda(), torch.from_numpy(fr[1]).cuda()
+    t = lambda f: torch.from_numpy(f[:, :, ::-1].astype(np.float32) / 255.0).permute(2, 0, 1).unsqueeze(0)
+    with torch.no_grad():
+        want = ifnet_ref.ifnet_forward({k: torch.from_numpy(v) for k, v in sd.items()}, t(fr[0]), t(fr[1]), 0.5)[0].permute(1, 2, 0).numpy()
+    res = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("FW_IFNET_SPLIT_TRUNK", split)
+        eng = RF.IFNetEngine("f16")
+        eng.load_state_dict(sd)
+        rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        u8 = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+        eng.interpolate_device(a, b, 0.5, out=u8, out_rgb_f32=rgb)
+        torch.cuda.synchronize()
+        res[split] = (rgb.cpu().numpy(), u8.cpu().numpy().astype(int))
+        eng.close()
+    e1, e0 = np.abs(res["1"][0] - want).max(), np.abs(res["0"][0] - want).max()
+    print(f"split trunk: max-abs vs oracle {e1:.2e} (fp32 trunk {e0:.2e}), split vs fp32 trunk {np.abs(res['1'][0] - res['0'][0]).max():.2e}")
+    assert e1 < 4e-3 and e0 < 4e-3 and e1 < 2 * e0 + 1e-4
+    assert np.abs(res["1"][0] - res["0"][0]).max() < 2e-3
+    assert np.abs(res["1"][1] - res["0"][1]).max() <= 1

@@ -379,7 +379,14 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
 #pragma unroll
                     for (int w = 0; w < NW; ++w)
 #pragma unroll
-                        for (int ph = 0; ph < 2; ++ph) acc[row][w][ph] = acc[row][w][ph] * p.s1;
+                        for (int ph = 0; ph < 2; ++ph) {
+                            f32x4 o = acc[row][w][ph] * p.s1;
+                            if (p.post_act) {   // IFNet's ResConv on a split trunk: LeakyReLU(0.2) after the residual add
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.2f * o[j]);
+                            }
+                            acc[row][w][ph] = o;
+                        }
             } else {
                 // (1) fp32 side: residuals in, trunk out.  Native layout = the accumulator fragment order
                 //     [tile][wave][row][w][ph][lane][4], one contiguous KiB per wave-instruction, no transposition;

@@ -158,6 +158,7 @@ struct Block {
     std::vector<float> h_w00, h_b00, h_w01, h_b01, h_wl, h_bl;   // host copies until finalize()
     std::vector<float> h_wr[NRES], h_br[NRES], h_beta[NRES];
     Conv conv00, conv01, res[NRES], last;
+    Conv res_split[NRES];   // cp == 64: the ResConvs with beta folded into weights and bias (split trunk: fw_ifnet::split_trunk)
     DevBuf beta[NRES];
     unsigned have = 0;   // bits: 0 w00, 1 b00, 2 w01, 3 b01, 4 wl, 5 bl, 6 + 3j (w), 7 + 3j (b), 8 + 3j (beta)
 };
@@ -183,6 +184,12 @@ struct fw_ifnet {
     bool merge_groups = true;   // the 64-channel output groups of a conv in one launch (FW_IFNET_MERGE_GROUPS=0: A/B)
     bool fuse_glue = true;      // an IFBlock's input in one kernel, depth-to-space inside the accumulate (FW_IFNET_FUSE_GLUE=0: A/B)
     bool native_trunk = true;   // the ResConv chain's fp32 trunk in the conv kernel's accumulator-native layout (FW_IFNET_NATIVE_TRUNK=0: A/B)
+    // A 64-channel IFBlock (the full-resolution one: eight ResConvs on a 270 x 480 map at 1080p, HBM-bound: 33 MB of fp32 trunk in and
+    // out per conv beside the typed tensor) keeps its trunk as two operand-typed tensors, hi = T(x) and lo = T(x - hi), like the RRDBNet
+    // (DESIGN.md section 2): hi is the tensor the next conv reads anyway and comes back as a residual from the tile already in LDS (an
+    // identity MFMA), lo is the only extra read; lrelu(conv(x) * beta + x) with beta folded into the conv's weights and bias
+    // (EPI_RESIDUAL_SPLIT).  68 instead of 100 MB per ResConv.  FW_IFNET_SPLIT_TRUNK=0: the fp32 trunk (A/B).
+    bool split_trunk = true;
     bool narrow_groups = true;  // 32-channel output groups for the conv chains of blocks with few tiles (FW_IFNET_NARROW=0: A/B;
     long narrow_below = 128;    //   FW_IFNET_NARROW_BELOW: below that many 64-channel workgroups per launch)
     bool warmed = false;
@@ -264,7 +271,7 @@ Plan make_plan(int H, int W) {
 }
 
 void run_conv(const fw_ifnet* n, const Conv& cv, const void* x, int h, int w, void* out, float* out_f32, int act, const float* res,
-              const float* beta, int post_act, hipStream_t st, bool trunk = false, bool narrow = false) {
+              const float* beta, int post_act, hipStream_t st, bool trunk = false, bool narrow = false, void* out_lo = nullptr) {
     const bool merged = n->merge_groups && cv.wall.p;
     narrow = narrow && merged && cv.nwall.p;
     for (const auto& g : cv.groups) {
@@ -283,6 +290,7 @@ void run_conv(const fw_ifnet* n, const Conv& cv, const void* x, int h, int w, vo
         p.out_cstride = cv.cout_pad;
         p.out_coff = g.off;
         p.out_f32 = out_f32;
+        p.out_lo = out_lo;
         p.res1 = res;
         p.s1 = 1.f;
         p.s2 = 1.f;
@@ -317,6 +325,35 @@ void run_conv(const fw_ifnet* n, const Conv& cv, const void* x, int h, int w, vo
     }
 }
 
+// lrelu(conv'(x) + x) on a split trunk: x = hi + lo (two typed NHWC tensors of 64 channels), conv' = the ResConv with beta folded in
+void run_resconv_split(const fw_ifnet* n, const Conv& cv, const void* x_hi, const void* x_lo, int h, int w, void* out_hi, void* out_lo,
+                       hipStream_t st) {
+    const auto& g = cv.groups.at(0);
+    ConvParams p{};
+    p.in = x_hi;
+    p.in_cstride = 64;
+    p.in_pstride = 32;
+    p.out_pstride = 32;
+    p.cin_chunks = 2;
+    p.H = h;
+    p.W = w;
+    p.wpk = g.w.p;
+    p.bias = (const float*)g.b.p;
+    p.out = out_hi;
+    p.out_lo = out_lo;
+    p.out_cstride = 64;
+    p.s1 = 1.f;
+    p.s2 = 1.f;
+    p.post_act = 1;
+    p.in_id_scale = 1.f;                                   // + hi, from the centre tap of the tile in LDS
+    p.n_id = 2;                                            // + lo, channels [0, 32) and [32, 64)
+    const long lo_off = (const char*)x_lo - (const char*)x_hi;
+    p.chunk_off[0] = lo_off;
+    p.chunk_off[1] = lo_off + 64;
+    p.id_scale[0] = p.id_scale[1] = 1.f;
+    launch_conv3x3(n->dt, 2, EPI_RESIDUAL_SPLIT, p, st);
+}
+
 void forward(fw_ifnet* n, const uint8_t* d0, const uint8_t* d1, int H, int W, float timestep, uint8_t* d_out, float* d_rgb,
              hipStream_t st) {
     const int Hp = pad_to(H, 32), Wp = pad_to(W, 32);
@@ -348,11 +385,21 @@ void forward(fw_ifnet* n, const uint8_t* d0, const uint8_t* d1, int H, int W, fl
         // chain: the native fp32 trunk's layout follows the group width.
         const long tiles = (long)(f32_native_elems(hf, wf, 1) / (512 * 32));
         const bool narrow = n->narrow_groups && tiles * (b.cp / 64) < n->narrow_below;
+        if (n->split_trunk && b.cp == 64 && !b.res_split[0].groups.empty()) {
+            // the trunk as hi + lo (the fp32 trunk's buffers hold the lo tensors: they are twice as large)
+            run_conv(n, b.conv01, u1, hf, wf, feat, nullptr, 1, nullptr, nullptr, 0, st, false, false, feat32);
+            for (int j = 0; j < NRES; ++j) {
+                run_resconv_split(n, b.res_split[j], feat, feat32, hf, wf, nxt, nxt32, st);
+                std::swap(feat, nxt);
+                std::swap(feat32, nxt32);
+            }
+        } else {
         run_conv(n, b.conv01, u1, hf, wf, feat, feat32, 1, nullptr, nullptr, 0, st, true, narrow);
         for (int j = 0; j < NRES; ++j) {   // ResConv: lrelu(conv(x) * beta + x)
             run_conv(n, b.res[j], feat, hf, wf, nxt, nxt32, 0, feat32, (const float*)b.beta[j].p, 1, st, true, narrow);
             std::swap(feat, nxt);
             std::swap(feat32, nxt32);
+        }
         }
         run_conv(n, b.last, feat, hf, wf, nullptr, t96, 0, nullptr, nullptr, 0, st);
         if (n->fuse_glue) {
@@ -398,6 +445,7 @@ int fw_ifnet_create(int device_id, int dtype, fw_ifnet** out) {
         if (const char* e = getenv("FW_IFNET_MERGE_GROUPS")) n->merge_groups = atoi(e) != 0;
         if (const char* e = getenv("FW_IFNET_FUSE_GLUE")) n->fuse_glue = atoi(e) != 0;
         if (const char* e = getenv("FW_IFNET_NATIVE_TRUNK")) n->native_trunk = atoi(e) != 0;
+        if (const char* e = getenv("FW_IFNET_SPLIT_TRUNK")) n->split_trunk = atoi(e) != 0;
         if (const char* e = getenv("FW_IFNET_NARROW")) n->narrow_groups = atoi(e) != 0;
         if (const char* e = getenv("FW_IFNET_NARROW_BELOW")) n->narrow_below = atol(e);
         for (int i = 0; i < NBLK; ++i) {
@@ -470,6 +518,14 @@ int fw_ifnet_finalize(fw_ifnet* n) {
                 std::vector<float> beta(b.cp, 0.f);
                 for (int k = 0; k < c; ++k) beta[k] = b.h_beta[j][k];
                 upload(b.beta[j], beta.data(), beta.size() * 4);
+                if (b.cp == 64) {
+                    std::vector<float> ws(b.h_wr[j]), bs(b.h_br[j]);
+                    for (int co = 0; co < c; ++co) {
+                        for (size_t k = 0; k < (size_t)c * 9; ++k) ws[(size_t)co * c * 9 + k] *= b.h_beta[j][co];
+                        bs[co] *= b.h_beta[j][co];
+                    }
+                    b.res_split[j].build(n->dt, ws, bs, c, c, b.cp, b.cp);
+                }
             }
             std::vector<float> w3, b3;
             convtranspose_as_3x3(b.h_wl.data(), b.h_bl.data(), c, 24, &w3, &b3);
@@ -602,6 +658,7 @@ int fw_ifnet_destroy(fw_ifnet* n) {
         b.last.release();
         for (int j = 0; j < NRES; ++j) {
             b.res[j].release();
+            b.res_split[j].release();
             b.beta[j].release();
         }
     }
