@@ -53,6 +53,8 @@ void upload(DevBuf& b, const void* src, size_t bytes) {
 // One 3x3 convolution [cout_pad][cin_pad] split into launches of 64 (or a last 32) output channels.
 struct Conv {
     int cin_pad = 0, cout_pad = 0;
+    int cin_chunks = 0;      // 32-channel chunks that hold real input channels: the K loop stops there (a 96-channel block pads its tensors to 128;
+                             // the fourth chunk of every input is zeros times zero weights)
     struct Group {
         DevBuf w, b;
         int ct = 0, off = 0;
@@ -78,6 +80,7 @@ struct Conv {
         release();
         cin_pad = cin_p;
         cout_pad = cout_p;
+        cin_chunks = (cin + 31) / 32;
         std::vector<float> wp((size_t)cout_p * cin_p * 9, 0.f), bp(cout_p, 0.f);
         for (int co = 0; co < cout; ++co) {
             for (int ci = 0; ci < cin; ++ci)
@@ -190,6 +193,7 @@ struct fw_ifnet {
     // identity MFMA), lo is the only extra read; lrelu(conv(x) * beta + x) with beta folded into the conv's weights and bias
     // (EPI_RESIDUAL_SPLIT).  68 instead of 100 MB per ResConv.  FW_IFNET_SPLIT_TRUNK=0: the fp32 trunk (A/B).
     bool split_trunk = true;
+    bool skip_pad_chunks = true;   // FW_IFNET_SKIP_PAD=0: walk the zero-padded input chunks as well (A/B)
     bool narrow_groups = true;  // 32-channel output groups for the conv chains of blocks with few tiles (FW_IFNET_NARROW=0: A/B;
     long narrow_below = 128;    //   FW_IFNET_NARROW_BELOW: below that many 64-channel workgroups per launch)
     bool warmed = false;
@@ -281,7 +285,7 @@ void run_conv(const fw_ifnet* n, const Conv& cv, const void* x, int h, int w, vo
         p.in_cstride = cv.cin_pad;
         p.in_pstride = 32;
         p.out_pstride = 32;
-        p.cin_chunks = cv.cin_pad / 32;
+        p.cin_chunks = n->skip_pad_chunks ? cv.cin_chunks : cv.cin_pad / 32;
         p.H = h;
         p.W = w;
         p.wpk = g.w.p;
@@ -446,6 +450,7 @@ int fw_ifnet_create(int device_id, int dtype, fw_ifnet** out) {
         if (const char* e = getenv("FW_IFNET_FUSE_GLUE")) n->fuse_glue = atoi(e) != 0;
         if (const char* e = getenv("FW_IFNET_NATIVE_TRUNK")) n->native_trunk = atoi(e) != 0;
         if (const char* e = getenv("FW_IFNET_SPLIT_TRUNK")) n->split_trunk = atoi(e) != 0;
+        if (const char* e = getenv("FW_IFNET_SKIP_PAD")) n->skip_pad_chunks = atoi(e) != 0;
         if (const char* e = getenv("FW_IFNET_NARROW")) n->narrow_groups = atoi(e) != 0;
         if (const char* e = getenv("FW_IFNET_NARROW_BELOW")) n->narrow_below = atol(e);
         for (int i = 0; i < NBLK; ++i) {
@@ -513,6 +518,7 @@ int fw_ifnet_finalize(fw_ifnet* n) {
                 for (int ci = 0; ci < c / 2; ++ci)
                     for (int t = 0; t < 9; ++t) w1[((size_t)co * b.c2p + ci) * 9 + t] = b.h_w01[((size_t)co * (c / 2) + ci) * 9 + t];
             b.conv01.build(n->dt, stride2_as_unshuffled(w1.data(), c, b.c2p), b.h_b01, c, 4 * b.c2p, 4 * b.c2p, b.cp, true);
+            b.conv01.cin_chunks = (4 * (c / 2) + 31) / 32;   // channel ci * 4 + sub of the unshuffled tensor: those of the padded ci >= c / 2 are zero
             for (int j = 0; j < NRES; ++j) {
                 b.res[j].build(n->dt, b.h_wr[j], b.h_br[j], c, c, b.cp, b.cp, true);
                 std::vector<float> beta(b.cp, 0.f);
