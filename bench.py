@@ -137,6 +137,47 @@ def ifnet_design_bytes(H, W):
     return total
 
 
+class PowerSampler:
+    """Socket power and sclk of one GPU while the timed region runs: `rocm-smi` as a child process every half second (it does not touch
+    this process's HIP state).  stop() -> {"power_w", "sclk_mhz", "samples"} (medians over the samples within 10 % of the highest power:
+    the region under load), or None when rocm-smi is missing or the run was too short for two samples."""
+
+    def __init__(self, device: int):
+        import shutil
+        import threading
+        self._exe = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+        self._dev, self._rows, self._stop = device, [], threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+        if self._exe:
+            self._th.start()
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self._stop.is_set():
+            try:
+                t = subprocess.run([self._exe, "-d", str(self._dev), "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+                pw = re.search(r"Power \(W\): ([\d.]+)", t)
+                sc = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", t)
+                if pw:
+                    self._rows.append((float(pw.group(1)), int(sc.group(1)) if sc else None))
+            except Exception:  # noqa: BLE001 - a sampler must never take the bench down
+                return
+            self._stop.wait(0.5)
+
+    def stop(self):
+        import statistics as st
+        self._stop.set()
+        if self._exe:
+            self._th.join(timeout=15)
+        if len(self._rows) < 2:
+            return None
+        top = max(p for p, _ in self._rows)
+        load = [(p, c) for p, c in self._rows if p > 0.9 * top]
+        clk = [c for _, c in load if c]
+        return {"power_w": st.median(p for p, _ in load), "sclk_mhz": st.median(clk) if clk else None, "samples": len(load)}
+
+
 def main():
     args = parse_args()
     import numpy as np
@@ -276,6 +317,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sampler = PowerSampler(dev_ord) if rank == 0 else None       # rocm-smi in a child process, twice a second: joules per step
     t0 = time.perf_counter()
     ev0.record()
     run_steps(steps)
@@ -284,6 +326,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    power = sampler.stop() if sampler is not None else None
     t = torch.tensor([wall], dtype=torch.float64, device=dev if (world == 1 or on_nccl) else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -313,7 +356,7 @@ def main():
                     note = f"profiles/{tf.name} was measured on another build or dtype: not quoted"
             roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
                     "traffic": traffic, "traffic_source": note,
-                    "kernel": "conv3x3_pair_slide_kernel + conv3x3_mfma_kernel (every conv launch of the Real-ESRGAN forward)",
+                    "kernel": "conv3x3_pair_slide_kernel + conv3x3_wino_split_kernel + conv3x3_mfma_kernel + conv_up2x_phase_kernel (every conv launch of the Real-ESRGAN forward; the pair kernel is 53 % of the frame)",
                     "launches_timed": launches, "avg_launch_ms": conv_ms / max(launches, 1),
                     "avg_launch_gflop": conv_flops / max(launches, 1) / 1e9}
         else:
@@ -404,6 +447,13 @@ def main():
             res["config"]["frame_tflop"] = flops_frame / 1e12
             if cfg == "sr":
                 res["whole_path_tflops_per_gpu"] = flops_frame * steps / (dev_ms * 1e-3) / 1e12
+        if power is not None:
+            # rank 0's GPU under load during the timed region: the conv kernels run pinned at the board's power limit, so
+            # joules per step, not cycles, is what a change has to lower
+            res["energy"] = {"power_w": power["power_w"], "sclk_mhz": power["sclk_mhz"], "samples": power["samples"],
+                             "joules_per_step_per_gpu": power["power_w"] * wall_max / steps}
+            if flops_frame is not None and cfg == "sr":
+                res["energy"]["pj_per_algorithmic_flop"] = power["power_w"] * (wall_max / steps) / flops_frame * 1e12
         if parity is not None:
             res["parity"] = parity
         if cpu is not None:

@@ -51,3 +51,27 @@ def test_traffic_profiles_are_tagged_with_a_build_digest():
         tj = json.loads(f.read_text())
         assert len(tj["lib_digest"]) == 16 and tj["hbm_bytes_per_forward"] > 1e9
     assert b.newest_profile("no_such_file.json") is None
+
+
+def test_power_sampler_never_takes_the_bench_down(tmp_path, monkeypatch):
+    """The `energy` object of a bench line comes from rocm-smi sampled in a child process; without the tool, without a GPU or with a run too
+    short for two samples the sampler answers None, and with samples it reports the medians of the region under load."""
+    b = _bench()
+    s = b.PowerSampler(0)
+    assert s.stop() is None or {"power_w", "sclk_mhz", "samples"} <= set(s.stop() or {"power_w": 0, "sclk_mhz": 0, "samples": 0})
+    # a stand-in rocm-smi: three samples under load, one idle
+    fake = tmp_path / "rocm-smi"
+    state = tmp_path / "n"
+    fake.write_text("#!/bin/bash\nn=$(cat %s 2>/dev/null || echo 0); echo $((n + 1)) > %s\n"
+                    "if [ $n -lt 3 ]; then p=1399.0; c=1750; else p=400.0; c=2400; fi\n"
+                    "echo \"GPU[0]\t\t: Current Socket Graphics Package Power (W): $p\"\necho \"GPU[0]\t\t: sclk clock level: 1: (${c}Mhz)\"\n" % (state, state))
+    fake.chmod(0o755)
+    monkeypatch.setenv("PATH", f"{tmp_path}:{os.environ['PATH']}")
+    s = b.PowerSampler(0)
+    import time
+    for _ in range(100):
+        if state.exists() and int(state.read_text() or 0) >= 4:
+            break
+        time.sleep(0.1)
+    r = s.stop()
+    assert r is not None and r["power_w"] == 1399.0 and r["sclk_mhz"] == 1750 and r["samples"] >= 3
